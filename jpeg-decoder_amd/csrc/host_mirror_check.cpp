@@ -1,0 +1,61 @@
+// host_mirror_check.cpp -- TEST TOOL.  Compiles jpeg_math.hpp (the device arithmetic) for the HOST
+// and checks it against the oracle, so the CPU-only suite pins the zigzag tables, the deferred
+// halvings / folded constants and the integer colour formulas before any GPU is involved.
+//   usage: host_mirror_check [n_blocks_per_kind=200000]
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "jpeg_math.hpp"
+#include "../../oracle/jpeg_oracle.h"
+
+using namespace jpegmath;
+
+static size_t check_blocks(size_t n, uint64_t seed, int kind, const jpeggpu_qtable_t &q) {
+   std::vector<jpeggpu_blocl16_t> in(n);
+   oracle_synth_blocks(in.data(), n, seed, 0, kind);
+   uint32_t qw[32];
+   for (int i = 0; i < 32; i++) qw[i] = q.data[2 * i] | ((uint32_t)q.data[2 * i + 1] << 16);
+   size_t bad = 0;
+   for (size_t b = 0; b < n; b++) {
+      jpeggpu_blocl16_t z = in[b];
+      jpeggpu_bloct16_t sq; jpeggpu_bloctu8_t want;
+      oracle_iquant(z.data, 0, 63, q.data);
+      oracle_izz(z.data, sq.data);
+      oracle_idct_opt(sq.data, want.data);
+      uint32_t zw[32]; memcpy(zw, in[b].data, 128);
+      float m[8][8]; uint2 rows[8];
+      dequant_izz(zw, qw, m);
+      idct_block(m, rows);
+      for (int r = 0; r < 8; r++)
+         for (int c = 0; c < 8; c++) {
+            uint8_t got = (uint8_t)(((c < 4 ? rows[r].x : rows[r].y) >> (8 * (c & 3))) & 0xFF);
+            if (got != want.data[c][r]) { bad++; r = 8; break; }
+         }
+   }
+   printf("host mirror idct kind %d: %zu blocks, %zu differing\n", kind, n, bad);
+   return bad;
+}
+
+int main(int argc, char **argv) {
+   size_t n = argc > 1 ? (size_t)atol(argv[1]) : 200000;
+   jpeggpu_qtable_t qa, qc;
+   for (int i = 0; i < 64; i++) { qa.data[i] = (uint16_t)(2 + i); qc.data[i] = (uint16_t)(40503u * (unsigned)(i + 1)); }
+   size_t bad = 0;
+   bad += check_blocks(n, 11, 0, qa);
+   bad += check_blocks(n, 12, 1, qa);
+   bad += check_blocks(n, 13, 2, qc);
+   size_t cbad = 0;
+   for (int y = 0; y < 256; y++)
+      for (int cb = 0; cb < 256; cb++)
+         for (int cr = 0; cr < 256; cr++) {
+            uint8_t want[3];
+            oracle_ycc2rgb_pixel((uint8_t)y, (uint8_t)cb, (uint8_t)cr, want);
+            uint32_t v = ycc_to_rgb(y, chroma_offsets(cb, cr));
+            cbad += (v != ((uint32_t)want[0] | ((uint32_t)want[1] << 8) | ((uint32_t)want[2] << 16)));
+         }
+   printf("host mirror ycc2rgb: 2^24 inputs, %zu differing\n", cbad);
+   bad += cbad;
+   printf(bad ? "host_mirror_check: FAILED\n" : "host_mirror_check: OK\n");
+   return bad != 0;
+}

@@ -1,0 +1,160 @@
+// jpeg_math.hpp -- device arithmetic of the pixel back end (gfx950).
+//
+// Bit-exact restatement of the reference's per-sample arithmetic, re-derived for the VALU:
+//   * iquant   src/iqzz.c:9-14       int16*uint16 wrapped to int16
+//   * idct_opt src/idct_opt.c:32-117  Loeffler 8-point, fp32 with three fp64 sites
+//   * ycc2rgb  src/ycc2rgb.c:12-22    all-fp64 colour conversion
+//
+// The fp64 sites and the IEEE fp32 divide are replaced by 2-instruction fp32 sequences
+// fma(x, Ch, x*Cl) whose result equals the reference rounding for EVERY float x; the colour
+// conversion is replaced by integer multiply-shift formulas that equal the reference on all 2^24
+// inputs.  Both claims are proven exhaustively by tools/explore_exact.c and tools/explore_color.c
+// (run by tests/test_exact_identities.py).  The file MUST be compiled with -ffp-contract=off:
+// every a*b+c below that is not an explicit fmaf() has two roundings in the reference.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+#define JM_HD __host__ __device__ __forceinline__
+
+namespace jpegmath {
+
+// ---- Loeffler constants -------------------------------------------------------------------
+// fast_idct_coef (src/idct_opt.c:27-30): double literals narrowed to float.
+#define JM_C1 ((float)0.9807852804)
+#define JM_S1 ((float)0.195090322)
+#define JM_C3 ((float)0.8314696123)
+#define JM_S3 ((float)0.555570233)
+#define JM_C6 ((float)0.3826834324)
+#define JM_S6 ((float)0.9238795325)
+// hi/lo float splits of the three irrational factors (tools/explore_exact.c, "bump 0"):
+//   1/SQRT_2 (double literal, src/idct_opt.c:8), 1/(float)SQRT_2 (parameter k, :64),
+//   SQRT_8 (:9).  Butterfly halvings (src/idct_opt.c:34-35) are exact power-of-two scalings, so
+//   they are deferred and folded into these constants: each 1-D transform carries a pending
+//   factor 2^-3 that the final normalisation constant absorbs (SQRT_8/8).
+#define JM_RH2 0x1.6a09e6p+0f    // 2 * hi(1/SQRT_2)
+#define JM_RL2 0x1.9fcef4p-26f   // 2 * lo(1/SQRT_2)
+#define JM_KH2 0x1.6a09e6p+0f    // 2 * hi(1/(float)SQRT_2)
+#define JM_KL2 0x1.9fcef4p-25f   // 2 * lo(1/(float)SQRT_2)
+#define JM_SH8 0x1.6a09e6p-2f    // hi(SQRT_8) / 8
+#define JM_SL8 0x1.9fcef4p-28f   // lo(SQRT_8) / 8
+
+// (float)((double)x * C) or (float)((double)x / C') as one multiply and one fma.
+JM_HD float mul_hl(float x, float hi, float lo) { return __builtin_fmaf(x, hi, x * lo); }
+
+// One 8-point inverse transform, in place: idct_opt_1D (src/idct_opt.c:56-81).
+// v[] in natural coefficient order on entry, sample order on exit.
+JM_HD void idct8(float (&v)[8]) {
+   // reorder (:49-54)
+   float t0 = v[0], t1 = v[4], t2 = v[2], t3 = v[6], t4 = v[7], t5 = v[3], t6 = v[5], t7 = v[1];
+   float a, b;
+   // stage 4 inverse (:58-61); pending scale of t4..t7 becomes 2^-1
+   a = t7 + t4; b = t7 - t4; t7 = a; t4 = b;
+   t5 = mul_hl(t5, JM_RH2, JM_RL2);
+   t6 = mul_hl(t6, JM_RH2, JM_RL2);
+   // stage 3 inverse (:62-66); t0..t3 -> 2^-1, t4..t7 -> 2^-2
+   a = t0 + t1; b = t0 - t1; t0 = a; t1 = b;
+   {
+      float x = mul_hl(t2, JM_KH2, JM_KL2), y = mul_hl(t3, JM_KH2, JM_KL2);   // 2*(t/k)
+      t2 = x * JM_C6 - y * JM_S6;
+      t3 = y * JM_C6 + x * JM_S6;
+   }
+   a = t4 + t6; b = t4 - t6; t4 = a; t6 = b;
+   a = t7 + t5; b = t7 - t5; t7 = a; t5 = b;
+   // stage 2 inverse (:67-71); t0..t3 -> 2^-2
+   a = t0 + t3; b = t0 - t3; t0 = a; t3 = b;
+   a = t1 + t2; b = t1 - t2; t1 = a; t2 = b;
+   {
+      float x = t4, y = t7;
+      t4 = x * JM_C3 - y * JM_S3;
+      t7 = y * JM_C3 + x * JM_S3;
+   }
+   {
+      float x = t5, y = t6;
+      t5 = x * JM_C1 - y * JM_S1;
+      t6 = y * JM_C1 + x * JM_S1;
+   }
+   // stage 1 inverse (:72-76); everything -> 2^-3
+   a = t0 + t7; b = t0 - t7; t0 = a; t7 = b;
+   a = t1 + t6; b = t1 - t6; t1 = a; t6 = b;
+   a = t2 + t5; b = t2 - t5; t2 = a; t5 = b;
+   a = t3 + t4; b = t3 - t4; t3 = a; t4 = b;
+   // normalisation (:77-80) with the pending 2^-3 folded in
+   v[0] = mul_hl(t0, JM_SH8, JM_SL8); v[1] = mul_hl(t1, JM_SH8, JM_SL8);
+   v[2] = mul_hl(t2, JM_SH8, JM_SL8); v[3] = mul_hl(t3, JM_SH8, JM_SL8);
+   v[4] = mul_hl(t4, JM_SH8, JM_SL8); v[5] = mul_hl(t5, JM_SH8, JM_SL8);
+   v[6] = mul_hl(t6, JM_SH8, JM_SL8); v[7] = mul_hl(t7, JM_SH8, JM_SL8);
+}
+
+// Level shift, clamp, truncate: src/idct_opt.c:110-113.
+JM_HD uint32_t to_u8(float s) {
+   float x = s + 128.0f;
+   x = __builtin_fminf(__builtin_fmaxf(x, 0.0f), 255.0f);   // inputs are never NaN
+   return (uint32_t)(int)x;
+}
+
+// 2-D transform of one block held as m[c][r] (column c, row r), idct_opt (src/idct_opt.c:93-117):
+// first along r for every column, then along c for every row.  Result packed as 8 raster rows of
+// 8 bytes: row[r] = {lo: columns 0..3, hi: columns 4..7}, byte c = sample (c, r).
+JM_HD void idct_block(float (&m)[8][8], uint2 (&row)[8]) {
+#pragma unroll
+   for (int c = 0; c < 8; c++) idct8(m[c]);
+#pragma unroll
+   for (int r = 0; r < 8; r++) {
+      float u[8];
+#pragma unroll
+      for (int c = 0; c < 8; c++) u[c] = m[c][r];
+      idct8(u);
+      row[r].x = to_u8(u[0]) | (to_u8(u[1]) << 8) | (to_u8(u[2]) << 16) | (to_u8(u[3]) << 24);
+      row[r].y = to_u8(u[4]) | (to_u8(u[5]) << 8) | (to_u8(u[6]) << 16) | (to_u8(u[7]) << 24);
+   }
+}
+
+// iquant (src/iqzz.c:12): product narrowed to int16 (wraps), then the int16 -> float conversion of
+// src/idct_opt.c:97.
+JM_HD float dequant_to_float(int zz, uint32_t q) {
+   return (float)(int)(short)(zz * (int)q);
+}
+
+// zigzag index -> (row, col): the scan pinned by test/iqzz_test.c:21-29.
+#define JM_ZZ_ROWS { 0,0,1,2,1,0,0,1, 2,3,4,3,2,1,0,0, 1,2,3,4,5,6,5,4, 3,2,1,0,0,1,2,3, \
+                     4,5,6,7,7,6,5,4, 3,2,1,2,3,4,5,6, 7,7,6,5,4,3,4,5, 6,7,7,6,5,6,7,7 }
+#define JM_ZZ_COLS { 0,1,0,0,1,2,3,2, 1,0,0,1,2,3,4,5, 4,3,2,1,0,0,1,2, 3,4,5,6,7,6,5,4, \
+                     3,2,1,0,1,2,3,4, 5,6,7,7,6,5,4,3, 2,3,4,5,6,7,7,6, 5,4,5,6,7,7,6,7 }
+
+// iquant + izz + int16->float for one block: zw = the 64 zigzag int16 as 32 little-endian words,
+// qw = the table packed the same way.  m[col][row] as izz stores it (src/iqzz.c:23).
+JM_HD void dequant_izz(const uint32_t (&zw)[32], const uint32_t (&qw)[32], float (&m)[8][8]) {
+   constexpr uint8_t ZR[64] = JM_ZZ_ROWS;
+   constexpr uint8_t ZC[64] = JM_ZZ_COLS;
+#pragma unroll
+   for (int i = 0; i < 32; i++) {
+      m[ZC[2 * i]][ZR[2 * i]] = dequant_to_float((int)(short)(zw[i] & 0xFFFF), qw[i] & 0xFFFF);
+      m[ZC[2 * i + 1]][ZR[2 * i + 1]] = dequant_to_float((int)zw[i] >> 16, qw[i] >> 16);
+   }
+}
+
+// ---- colour conversion, src/ycc2rgb.c:18-22 -------------------------------------------------
+// r = clamp8(y + ((91881*(cr-128) + 100) >> 16)), b = clamp8(y + ((116130*(cb-128) + 128) >> 16)),
+// g = clamp8(y + ((120 - 2886855*(cb-128) - 5990640*(cr-128)) >> 23) - fix) where fix = 1 only
+// for (cb, cr) = (28, 228) and 94 <= y <= 165: there the real-number offset is exactly -37 and the
+// reference's double evaluation lands just below the integer (tools/explore_color.c).
+struct ChromaOff { int r, g, b, fix; };
+JM_HD ChromaOff chroma_offsets(int cb, int cr) {
+   ChromaOff o;
+   o.r = (91881 * cr + (100 - 91881 * 128)) >> 16;
+   o.b = (116130 * cb + (128 - 116130 * 128)) >> 16;
+   o.g = ((120 + 2886855 * 128 + 5990640 * 128) - 2886855 * cb - 5990640 * cr) >> 23;
+   o.fix = (cb == 28) & (cr == 228);
+   return o;
+}
+JM_HD int clamp8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+// returns r | g<<8 | b<<16
+JM_HD uint32_t ycc_to_rgb(int y, const ChromaOff &o) {
+   int g = y + o.g - (o.fix & ((unsigned)(y - 94) < 72u));
+   return (uint32_t)clamp8(y + o.r) | ((uint32_t)clamp8(g) << 8) | ((uint32_t)clamp8(y + o.b) << 16);
+}
+
+}  // namespace jpegmath

@@ -1,0 +1,45 @@
+// kernels.h -- launch interface between the C-ABI layer (capi.cpp) and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace jpeggpu_k {
+
+// One launch of the fused back end: a batch of same-geometry frames, cut into tiles of
+// T MCUs x 1 MCU row.  Filled by plan_backend() in capi.cpp.
+struct BackendParams {
+   const void *coef[3];            // device plane pointers of frame 0 (blocl16_t arrays)
+   void *out;                      // device raster of frame 0
+   uint64_t coef_frame_stride[3];  // bytes between consecutive frames' planes
+   uint64_t out_stride;            // bytes between raster rows
+   uint64_t out_frame_stride;      // bytes between consecutive frames' rasters
+   uint32_t width;                 // pixels per raster row (crop)
+   uint32_t nbcomp;                // 1 or 3
+   uint32_t apply_iquant;
+   uint32_t T;                     // MCUs per tile
+   uint32_t B;                     // blocks per tile = T * sum(hs*vs)
+   uint32_t tile_w;                // pixels per tile row  = T * max_h * 8
+   uint32_t tile_rows;             // raster rows per tile = max_v * 8
+   uint32_t wq_shift;              // log2(tile_w/4) when that is a power of two, else 32
+   uint32_t nbH[3];                // blocks per plane row (nbmcuH*hs)
+   uint32_t vs[3];                 // block rows per MCU row
+   uint32_t bw[3];                 // blocks per tile row of component c = T*hs
+   uint32_t boff[4];               // first tile-block index of component c; boff[nbcomp] == B
+   uint32_t hf[3], vf[3];          // upsampling factors max_h/hs, max_v/vs (src/decoder_utils.c:102-107)
+   uint32_t plane_off[3];          // LDS byte offset of component c's u8 plane
+   uint32_t idq[3];
+   uint32_t qt[4][32];             // quantisation tables, zigzag order, two uint16 per word
+};
+
+struct LaunchDims { uint32_t tiles_per_row, mcu_rows, frames, threads; size_t lds_bytes; };
+
+hipError_t launch_backend(const BackendParams &p, const LaunchDims &d, hipStream_t s);
+
+// stage-level kernels (device pointers)
+hipError_t launch_iquant(void *d_blocks, size_t n, int s_start, int s_end, const uint32_t qt_packed[32], hipStream_t s);
+hipError_t launch_izz(const void *d_in, void *d_out, size_t n, hipStream_t s);
+hipError_t launch_idct(const void *d_in, void *d_out, size_t n, hipStream_t s);
+hipError_t launch_ycc2rgb(const uint8_t *d_y, const uint8_t *d_cb, const uint8_t *d_cr, uint8_t *d_rgb, size_t n, hipStream_t s);
+
+}  // namespace jpeggpu_k

@@ -1,0 +1,260 @@
+// kernels.hip -- HIP kernels of the JPEG pixel back end for gfx950 (MI355X).
+//
+// backend_kernel: the fused path  iquant + izz + idct_opt + upsample + ycc2rgb + raster store.
+//   One workgroup = one tile of T MCUs in one MCU row; one thread = one 8x8 block.
+//   phase 0  coalesced 16-byte loads of the tile's blocl16_t records -> LDS (XOR-swizzled so that
+//            the per-thread 128-byte reads of phase 1 are bank-conflict free)
+//   phase 1  each thread pulls its 64 coefficients into registers, dequantises, and runs both
+//            1-D passes of the Loeffler IDCT in registers (the inverse zigzag and the transpose
+//            between the passes are register renamings, not data movement), then writes its
+//            8 rows of 8 samples into the component's raster plane in LDS (aliasing the
+//            coefficient staging area, which is dead by then)
+//   phase 2  threads walk the tile's pixels 4 at a time: replicate-upsampled chroma fetch
+//            (px = x/hf, py = y/vf, src/decoder_utils.c:72-80), integer colour conversion, and
+//            12-byte coalesced stores into the RGB raster (width cropped, rows not).
+//
+// Compiled with -ffp-contract=off (see jpeg_math.hpp).
+#include <hip/hip_runtime.h>
+#include "jpeg_math.hpp"
+#include "kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace jpeggpu_k {
+
+using namespace jpegmath;
+
+struct __attribute__((packed, aligned(4))) rgb4_t { uint32_t a, b, c; };
+
+__device__ __forceinline__ void decode_block(const BackendParams &p, uint32_t b, uint32_t &c, uint32_t &by, uint32_t &bxl) {
+   c = (p.nbcomp == 3) ? (uint32_t)(b >= p.boff[1]) + (uint32_t)(b >= p.boff[2]) : 0u;
+   uint32_t r = b - p.boff[c];
+   uint32_t w = p.bw[c];
+   by = (uint32_t)(r >= w) + (uint32_t)(r >= 2 * w) + (uint32_t)(r >= 3 * w);
+   bxl = r - by * w;
+}
+
+// store up to 4 pixels (12 bytes) whose first byte is dst; n = number of valid pixels (1..4)
+__device__ __forceinline__ void store_rgb_quad(uint8_t *dst, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t n) {
+   if (n == 4 && ((uintptr_t)dst & 3) == 0) {
+      rgb4_t v = { w0, w1, w2 };
+      *reinterpret_cast<rgb4_t *>(dst) = v;
+   } else {
+      uint32_t w[3] = { w0, w1, w2 };
+#pragma unroll
+      for (uint32_t i = 0; i < 12; i++)
+         if (i < 3 * n) dst[i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
+   }
+}
+
+template <int HFC, int VFC>   // chroma factors; 0 = generic path (any factors, any component)
+__global__ void __launch_bounds__(512) backend_kernel(const BackendParams p) {
+   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+   uint4 *stage = reinterpret_cast<uint4 *>(lds);
+   const uint32_t tid = threadIdx.x, nt = blockDim.x;
+   const uint32_t tile = blockIdx.x, m = blockIdx.y, frame = blockIdx.z;
+   uint32_t *qt_lds = reinterpret_cast<uint32_t *>(lds + (size_t)nt * 128);
+
+   // ---- phase 0: tile coefficients -> LDS --------------------------------------------------
+   if (p.apply_iquant && tid < 128) qt_lds[tid] = p.qt[tid >> 5][tid & 31];
+   for (uint32_t j = tid; j < p.B * 8; j += nt) {
+      uint32_t b = j >> 3, k = (j & 7) ^ ((b >> 1) & 7);
+      uint32_t c, by, bxl;
+      decode_block(p, b, c, by, bxl);
+      uint32_t col = tile * p.bw[c] + bxl;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (col < p.nbH[c]) {
+         const uint8_t *src = static_cast<const uint8_t *>(p.coef[c]) + (size_t)frame * p.coef_frame_stride[c] +
+                              (((size_t)m * p.vs[c] + by) * p.nbH[c] + col) * 128 + k * 16;
+         v = *reinterpret_cast<const uint4 *>(src);
+      }
+      stage[j] = v;
+   }
+   __syncthreads();
+
+   // ---- phase 1: one block per thread -------------------------------------------------------
+   const bool active = tid < p.B;
+   uint32_t c = 0, by = 0, bxl = 0;
+   uint2 rows[8];
+   {
+      float mtx[8][8];
+      if (active) {
+         decode_block(p, tid, c, by, bxl);
+         const uint4 *q4 = reinterpret_cast<const uint4 *>(qt_lds + p.idq[c] * 32);
+         uint32_t zw[32], qw[32];
+#pragma unroll
+         for (int k = 0; k < 8; k++) {
+            uint4 v = stage[tid * 8 + (k ^ ((tid >> 1) & 7))];
+            uint4 q = make_uint4(0x00010001u, 0x00010001u, 0x00010001u, 0x00010001u);
+            if (p.apply_iquant) q = q4[k];
+            zw[4 * k] = v.x; zw[4 * k + 1] = v.y; zw[4 * k + 2] = v.z; zw[4 * k + 3] = v.w;
+            qw[4 * k] = q.x; qw[4 * k + 1] = q.y; qw[4 * k + 2] = q.z; qw[4 * k + 3] = q.w;
+         }
+         dequant_izz(zw, qw, mtx);
+      }
+      __syncthreads();   // staging area is dead from here on; planes alias it
+      if (active) idct_block(mtx, rows);
+   }
+   if (active) {
+      uint8_t *plane = lds + p.plane_off[c] + (size_t)(by * 8) * (p.bw[c] * 8) + bxl * 8;
+#pragma unroll
+      for (int r = 0; r < 8; r++) *reinterpret_cast<uint2 *>(plane + (size_t)r * (p.bw[c] * 8)) = rows[r];
+   }
+   __syncthreads();
+
+   // ---- phase 2: upsample + colour convert + store ------------------------------------------
+   const uint32_t x0 = tile * p.tile_w;
+   if (x0 >= p.width) return;
+   const uint32_t wq = p.tile_w >> 2;                       // quads per tile row
+   const uint32_t nitems = wq * p.tile_rows;
+   uint8_t *out = static_cast<uint8_t *>(p.out) + (size_t)frame * p.out_frame_stride +
+                  (size_t)m * p.tile_rows * p.out_stride;
+   const uint32_t pitch0 = p.bw[0] * 8;
+   if (p.nbcomp == 1) {
+      // save_mcu_ligne_bw (src/decoder_utils.c:48-63): straight copy of the luma plane
+      for (uint32_t it = tid; it < nitems; it += nt) {
+         uint32_t y = (p.wq_shift < 32) ? (it >> p.wq_shift) : (it / wq), x = (it - y * wq) * 4;
+         if (x0 + x >= p.width) continue;
+         uint32_t n = min(4u, p.width - (x0 + x));
+         uint32_t v = *reinterpret_cast<const uint32_t *>(lds + p.plane_off[0] + y * pitch0 + x);
+         uint8_t *dst = out + (size_t)y * p.out_stride + x0 + x;
+         if (n == 4 && ((uintptr_t)dst & 3) == 0) *reinterpret_cast<uint32_t *>(dst) = v;
+         else for (uint32_t i = 0; i < n; i++) dst[i] = (uint8_t)(v >> (8 * i));
+      }
+      return;
+   }
+   const uint32_t pitch1 = p.bw[1] * 8, pitch2 = p.bw[2] * 8;
+   const uint8_t *pl0 = lds + p.plane_off[0], *pl1 = lds + p.plane_off[1], *pl2 = lds + p.plane_off[2];
+   for (uint32_t it = tid; it < nitems; it += nt) {
+      uint32_t y = (p.wq_shift < 32) ? (it >> p.wq_shift) : (it / wq), x = (it - y * wq) * 4;
+      if (x0 + x >= p.width) continue;
+      uint32_t n = min(4u, p.width - (x0 + x));
+      uint32_t px[4];
+      if constexpr (HFC != 0) {
+         // Y at full resolution, Cb and Cr share (HFC, VFC)
+         uint32_t yy = *reinterpret_cast<const uint32_t *>(pl0 + y * pitch0 + x);
+         uint32_t cy = y / VFC;
+         uint32_t cbw, crw;
+         if (HFC == 1) {
+            cbw = *reinterpret_cast<const uint32_t *>(pl1 + cy * pitch1 + x);
+            crw = *reinterpret_cast<const uint32_t *>(pl2 + cy * pitch2 + x);
+         } else {
+            cbw = *reinterpret_cast<const uint16_t *>(pl1 + cy * pitch1 + (x >> 1));
+            crw = *reinterpret_cast<const uint16_t *>(pl2 + cy * pitch2 + (x >> 1));
+         }
+#pragma unroll
+         for (int i = 0; i < 4; i++) {
+            int ci = (HFC == 1) ? i : (i >> 1);
+            ChromaOff o = chroma_offsets((cbw >> (8 * ci)) & 0xFF, (crw >> (8 * ci)) & 0xFF);
+            px[i] = ycc_to_rgb((yy >> (8 * i)) & 0xFF, o);
+         }
+      } else {
+         // generic replicate upsampling, any integer factors (src/decoder_utils.c:72-80)
+#pragma unroll
+         for (int i = 0; i < 4; i++) {
+            uint32_t xx = x + i;
+            int s0 = pl0[(y / p.vf[0]) * pitch0 + xx / p.hf[0]];
+            int s1 = pl1[(y / p.vf[1]) * pitch1 + xx / p.hf[1]];
+            int s2 = pl2[(y / p.vf[2]) * pitch2 + xx / p.hf[2]];
+            px[i] = ycc_to_rgb(s0, chroma_offsets(s1, s2));
+         }
+      }
+      uint32_t w0 = px[0] | (px[1] << 24);
+      uint32_t w1 = (px[1] >> 8) | (px[2] << 16);
+      uint32_t w2 = (px[2] >> 16) | (px[3] << 8);
+      store_rgb_quad(out + (size_t)y * p.out_stride + (size_t)(x0 + x) * 3, w0, w1, w2, n);
+   }
+}
+
+hipError_t launch_backend(const BackendParams &p, const LaunchDims &d, hipStream_t s) {
+   dim3 grid(d.tiles_per_row, d.mcu_rows, d.frames), block(d.threads);
+   void (*k)(const BackendParams) = backend_kernel<0, 0>;
+   if (p.nbcomp == 3 && p.hf[0] == 1 && p.vf[0] == 1 && p.hf[1] == p.hf[2] && p.vf[1] == p.vf[2]) {
+      uint32_t h = p.hf[1], v = p.vf[1];
+      if (h == 1 && v == 1) k = backend_kernel<1, 1>;
+      else if (h == 2 && v == 1) k = backend_kernel<2, 1>;
+      else if (h == 2 && v == 2) k = backend_kernel<2, 2>;
+      else if (h == 1 && v == 2) k = backend_kernel<1, 2>;
+   }
+   if (d.lds_bytes > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d.lds_bytes);
+      if (e != hipSuccess) return e;
+   }
+   hipLaunchKernelGGL(k, grid, block, d.lds_bytes, s, p);
+   return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage-level kernels: the four function contracts over arrays (parity isolation, not the hot path)
+// ------------------------------------------------------------------------------------------
+struct QtArg { uint32_t w[32]; };
+
+__global__ void iquant_kernel(int16_t *blocks, size_t n, int s0, int s1, QtArg q) {
+   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // one coefficient per thread
+   if (i >= n * 64) return;
+   int k = (int)(i & 63);
+   if (k < s0 || k > s1) return;
+   uint32_t qq = (q.w[k >> 1] >> (16 * (k & 1))) & 0xFFFF;
+   blocks[i] = (int16_t)(short)((int)blocks[i] * (int)qq);
+}
+
+__global__ void izz_kernel(const int16_t *in, int16_t *out, size_t n) {
+   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // one coefficient per thread
+   if (i >= n * 64) return;
+   constexpr uint8_t ZR[64] = JM_ZZ_ROWS;
+   constexpr uint8_t ZC[64] = JM_ZZ_COLS;
+   int k = (int)(i & 63);
+   out[(i & ~(size_t)63) + ZC[k] * 8 + ZR[k]] = in[i];        // data[col][row], src/iqzz.c:23
+}
+
+__global__ void idct_kernel(const int16_t *in, uint8_t *out, size_t n) {
+   size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // one block per thread
+   if (b >= n) return;
+   float mtx[8][8];
+   const int16_t *src = in + b * 64;
+#pragma unroll
+   for (int c = 0; c < 8; c++)
+#pragma unroll
+      for (int r = 0; r < 8; r++) mtx[c][r] = (float)src[c * 8 + r];   // bloct16_t data[col][row]
+   uint2 rows[8];
+   idct_block(mtx, rows);
+   uint8_t *dst = out + b * 64;                                         // bloctu8_t data[col][row]
+#pragma unroll
+   for (int r = 0; r < 8; r++) {
+#pragma unroll
+      for (int c = 0; c < 8; c++) dst[c * 8 + r] = (uint8_t)(((c < 4 ? rows[r].x : rows[r].y) >> (8 * (c & 3))) & 0xFF);
+   }
+}
+
+__global__ void ycc2rgb_kernel(const uint8_t *y, const uint8_t *cb, const uint8_t *cr, uint8_t *rgb, size_t n) {
+   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n) return;
+   uint32_t v = ycc_to_rgb(y[i], chroma_offsets(cb[i], cr[i]));
+   rgb[3 * i] = (uint8_t)v; rgb[3 * i + 1] = (uint8_t)(v >> 8); rgb[3 * i + 2] = (uint8_t)(v >> 16);
+}
+
+static inline unsigned nblocks(size_t work, unsigned per) { return (unsigned)((work + per - 1) / per); }
+
+hipError_t launch_iquant(void *d_blocks, size_t n, int s_start, int s_end, const uint32_t qt_packed[32], hipStream_t s) {
+   if (n == 0) return hipSuccess;
+   QtArg q; for (int i = 0; i < 32; i++) q.w[i] = qt_packed[i];
+   hipLaunchKernelGGL(iquant_kernel, dim3(nblocks(n * 64, 256)), dim3(256), 0, s, static_cast<int16_t *>(d_blocks), n, s_start, s_end, q);
+   return hipGetLastError();
+}
+hipError_t launch_izz(const void *d_in, void *d_out, size_t n, hipStream_t s) {
+   if (n == 0) return hipSuccess;
+   hipLaunchKernelGGL(izz_kernel, dim3(nblocks(n * 64, 256)), dim3(256), 0, s, static_cast<const int16_t *>(d_in), static_cast<int16_t *>(d_out), n);
+   return hipGetLastError();
+}
+hipError_t launch_idct(const void *d_in, void *d_out, size_t n, hipStream_t s) {
+   if (n == 0) return hipSuccess;
+   hipLaunchKernelGGL(idct_kernel, dim3(nblocks(n, 64)), dim3(64), 0, s, static_cast<const int16_t *>(d_in), static_cast<uint8_t *>(d_out), n);
+   return hipGetLastError();
+}
+hipError_t launch_ycc2rgb(const uint8_t *d_y, const uint8_t *d_cb, const uint8_t *d_cr, uint8_t *d_rgb, size_t n, hipStream_t s) {
+   if (n == 0) return hipSuccess;
+   hipLaunchKernelGGL(ycc2rgb_kernel, dim3(nblocks(n, 256)), dim3(256), 0, s, d_y, d_cb, d_cr, d_rgb, n);
+   return hipGetLastError();
+}
+
+}  // namespace jpeggpu_k

@@ -1,0 +1,54 @@
+"""Shared helpers for the parity tests: frame construction and synthetic coefficient planes."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import pyoracle  # noqa: E402
+
+# shaun_the_sheep.jpeg's two quantisation tables (zigzag order); the same values the reference's
+# own header test pins as literals (test/entete_test.c:201-218).  Loaded from the golden fixture.
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def qtables_ramp():
+    qa = np.array([2 + i for i in range(64)], dtype=np.uint16)
+    qb = np.array([3 + 2 * i for i in range(64)], dtype=np.uint16)
+    qc = np.array([(40503 * (i + 1)) & 0xFFFF for i in range(64)], dtype=np.uint16)  # wraps int16 products
+    return [qa, qb, qc, None]
+
+
+def oracle_desc(width, height, sampling, idq=None, apply_iquant=True):
+    """FrameDesc built WITHOUT the product library (oracle geometry), usable on CPU-only hosts."""
+    d = pyoracle.FrameDesc()
+    d.width, d.height, d.nbcomp = width, height, len(sampling)
+    d.apply_iquant = 1 if apply_iquant else 0
+    for c, (hs, vs) in enumerate(sampling[:3]):
+        d.comp[c].hs, d.comp[c].vs = hs, vs
+        d.comp[c].idq = idq[c] if idq is not None else (0 if c == 0 else 1)
+    rc, d = pyoracle.frame_geometry(d)
+    assert rc == 0, rc
+    return d
+
+
+def to_gpu_desc(jg, d):
+    return jg.FrameDesc.from_buffer_copy(bytes(d))
+
+
+def plane_shape(d, c):
+    return (d.nbmcuV * d.comp[c].vs * d.nbmcuH * d.comp[c].hs, 64)
+
+
+def synth_planes(d, seed, kind=0):
+    return [pyoracle.synth_blocks(plane_shape(d, c)[0], seed + c, 0, kind) for c in range(d.nbcomp)]
+
+
+def fnv1a64(a):
+    """FNV-1a over 8-byte words (vectorised xor-fold variant is NOT FNV; keep it simple and exact)."""
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
