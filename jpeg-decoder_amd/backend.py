@@ -41,6 +41,27 @@ lib_path = os.path.join(os.path.dirname(os.path.realpath(__file__)), "libjpeggpu
 if not os.path.exists(lib_path):
     raise ImportError(f"{lib_path} is missing: build it with `make -C jpeg-decoder_amd/csrc` "
                       "(or __graft_entry__.build()); there is no CPU fallback")
+
+
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME
+    libamdhip64.so.7, the same as /opt/rocm's).  If libjpeggpu.so pulled in the system copy and
+    torch later loaded its own, the process would hold two runtimes and torch would see no GPU.
+    Loading torch's copy first (without importing torch) makes both resolve to the same object,
+    whatever the import order."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass
+
+
+_preload_hip_runtime()
 lib = C.CDLL(lib_path)
 
 _vp, _sz, _u8p = C.c_void_p, C.c_size_t, C.POINTER(C.c_uint8)

@@ -15,6 +15,7 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def gpu():
     """The product library bound to device 0.  Fails loudly (no CPU fallback) without a GPU."""
+    import torch  # noqa: F401  first, so that the process holds ONE HIP runtime (torch bundles its own)
     import jpeg_decoder_amd as jg
     jg.init(0)
     return jg

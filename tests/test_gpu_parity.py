@@ -1,0 +1,208 @@
+"""GPU suite (-m gpu): the HIP path, called through the C ABI, against the oracle and the golden
+fixtures.  Bar: bit-exact (integer/byte outputs)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+orc = pyoracle.oracle
+G = helpers.GOLDEN
+QT = helpers.qtables_ramp()
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+# ---- stage-level contracts ---------------------------------------------------------------------
+
+def test_izz_known_answer(gpu):
+    from test_oracle_golden import ZZ_TABLE
+    assert np.array_equal(gpu.izz_blocks(np.arange(64, dtype=np.int16)[None, :])[0].T, ZZ_TABLE)
+
+
+def test_iquant_identity_and_band(gpu):
+    q = np.arange(64, dtype=np.uint16)
+    line = ((np.arange(64) + 1) * 2).astype(np.int16)
+    assert np.array_equal(gpu.iquant_blocks(line[None, :], 0, 63, q)[0].astype(np.int32), q.astype(np.int32) * line)
+    v = np.load(os.path.join(G, "stage_vectors.npz"))
+    assert np.array_equal(gpu.iquant_blocks(v["blocks"], 5, 20, v["q_ramp"]), v["iquant_band_5_20"])
+    assert np.array_equal(gpu.iquant_blocks(v["blocks"], 63, 63, v["q_wrap"]), orc.iquant_blocks(v["blocks"], 63, 63, v["q_wrap"]))
+
+
+def test_stage_vectors_from_reference(gpu):
+    v = np.load(os.path.join(G, "stage_vectors.npz"))
+    for name in ("ramp", "wrap"):
+        dq = gpu.iquant_blocks(v["blocks"], 0, 63, v[f"q_{name}"])
+        assert np.array_equal(dq, v[f"iquant_{name}"])
+        zz = gpu.izz_blocks(dq)
+        assert np.array_equal(zz, v[f"izz_{name}"])
+        assert np.array_equal(gpu.idct_opt_blocks(zz), v[f"idct_{name}"])
+
+
+@pytest.mark.parametrize("kind,n", [(0, 300000), (1, 200000), (2, 200000)])
+def test_idct_random_blocks_vs_oracle(gpu, kind, n):
+    blk = pyoracle.synth_blocks(n, 0xC0FFEE + kind, 0, kind)
+    zz = orc.izz_blocks(orc.iquant_blocks(blk, 0, 63, QT[2 if kind == 2 else 0]))
+    assert np.array_equal(gpu.idct_opt_blocks(zz), orc.idct_opt_blocks(zz))
+
+
+def test_idct_property_within_one_of_slow_idct(gpu):
+    from test_oracle_golden import slow_idct
+    rng = np.random.default_rng(2)
+    blocks = rng.integers(0, 256, size=(10000, 8, 8)).astype(np.int16)   # test/idct_opt_test.c:26
+    assert np.max(np.abs(gpu.idct_opt_blocks(blocks).astype(np.float64) - np.floor(slow_idct(blocks)))) <= 1
+
+
+def test_ycc2rgb_every_input(gpu):
+    meta = json.load(open(os.path.join(G, "meta.json")))
+    idx = np.arange(1 << 24, dtype=np.uint32)
+    rgb = gpu.ycc2rgb_pixels(idx & 255, (idx >> 8) & 255, (idx >> 16) & 255)
+    assert sha(rgb) == meta["ycc2rgb_all_sha256"]
+
+
+# ---- frame-level back end -------------------------------------------------------------------------
+
+def frame_cases():
+    meta = json.load(open(os.path.join(G, "meta.json")))
+    return sorted(meta["frames"].items())
+
+
+@pytest.mark.parametrize("key,info", frame_cases())
+def test_frame_vectors_from_reference(gpu, key, info):
+    d = helpers.oracle_desc(info["width"], info["height"], [tuple(s) for s in info["sampling"]], idq=info["idq"],
+                            apply_iquant=bool(info["apply_iquant"]))
+    planes = helpers.synth_planes(d, info["seed"], info["kind"])
+    out = gpu.backend_run(helpers.to_gpu_desc(gpu, d), planes, QT)
+    assert out.shape[0] == info["rows"]
+    assert sha(out) == info["sha256"]
+
+
+@pytest.mark.parametrize("stem,gold", [("invader_normal", "invader.pgm"), ("shaun_the_sheep", "shaun_the_sheep.ppm")])
+def test_reference_golden_files(gpu, stem, gold):
+    z = np.load(os.path.join(G, stem + "_planes.npz"))
+    d = gpu.FrameDesc.from_buffer_copy(z["desc"].tobytes())
+    planes = [z[f"plane{c}"] for c in range(d.nbcomp)]
+    qts = [z["qtables"][i] if z["qt_present"][i] else None for i in range(4)]
+    out = gpu.backend_run(d, planes, qts)
+    hdr = f"P{6 if d.nbcomp == 3 else 5}\n{d.width} {d.height}\n255\n".encode()
+    assert hdr + out.tobytes() == open(os.path.join(G, gold), "rb").read()
+
+
+WIDTHS = [(1, 1), (7, 9), (8, 8), (9, 17), (63, 16), (64, 64), (65, 33), (255, 31), (257, 8), (1023, 24), (1025, 16), (2049, 9), (4099, 17)]
+SAMPLINGS = [((1, 1),), ((1, 1),) * 3, ((2, 1), (1, 1), (1, 1)), ((2, 2), (1, 1), (1, 1)), ((1, 2), (1, 1), (1, 1)),
+             ((4, 1), (1, 1), (1, 1)), ((2, 2), (2, 1), (1, 2)), ((4, 2), (2, 2), (1, 1))]
+
+
+@pytest.mark.parametrize("samp", SAMPLINGS, ids=lambda s: "_".join(f"{a}{b}" for a, b in s))
+def test_ragged_sizes_vs_oracle(gpu, samp):
+    """Edge tiles, width crop, padded rows, every alignment of the raster row start."""
+    for i, (w, h) in enumerate(WIDTHS):
+        for aq in (True, False):
+            d = helpers.oracle_desc(w, h, samp, apply_iquant=aq)
+            planes = helpers.synth_planes(d, 500 + i, kind=0 if aq else 1)
+            want = orc.backend_run(d, planes, QT)
+            got = gpu.backend_run(helpers.to_gpu_desc(gpu, d), planes, QT)
+            assert np.array_equal(want, got), (samp, w, h, aq)
+
+
+def test_out_stride_and_untouched_padding(gpu):
+    d = helpers.oracle_desc(301, 50, ((2, 2), (1, 1), (1, 1)))
+    planes = helpers.synth_planes(d, 42)
+    want = orc.backend_run(d, planes, QT)
+    stride = 301 * 3 + 13
+    buf = np.full((want.shape[0], stride), 0xAB, dtype=np.uint8)
+    got = gpu.backend_run(helpers.to_gpu_desc(gpu, d), planes, QT, out=buf, out_stride=stride)
+    assert np.array_equal(got[:, :903], want)
+    assert np.all(got[:, 903:] == 0xAB)
+
+
+def test_full_int16_range_and_wrap(gpu):
+    d = helpers.oracle_desc(640, 64, ((2, 2), (1, 1), (1, 1)), idq=[2, 2, 2])
+    planes = helpers.synth_planes(d, 7, kind=2)
+    assert np.array_equal(orc.backend_run(d, planes, QT), gpu.backend_run(helpers.to_gpu_desc(gpu, d), planes, QT))
+
+
+def test_zero_and_dc_only_frames(gpu):
+    d = helpers.oracle_desc(128, 32, ((2, 1), (1, 1), (1, 1)))
+    planes = [np.zeros(helpers.plane_shape(d, c), np.int16) for c in range(3)]
+    out = gpu.backend_run(helpers.to_gpu_desc(gpu, d), planes, QT)
+    assert np.array_equal(out, orc.backend_run(d, planes, QT)) and np.all(out == 128)
+    for c in range(3):
+        planes[c][:, 0] = np.arange(planes[c].shape[0]) % 257 - 128
+    assert np.array_equal(gpu.backend_run(helpers.to_gpu_desc(gpu, d), planes, QT), orc.backend_run(d, planes, QT))
+
+
+def test_special_chroma_pair_reaches_the_fused_kernel(gpu):
+    """(cb, cr) = (28, 228): the one chroma pair whose green offset depends on y."""
+    d = helpers.oracle_desc(256, 8, ((1, 1),) * 3, apply_iquant=False)
+    planes = [np.zeros(helpers.plane_shape(d, c), np.int16) for c in range(3)]
+    planes[0][:, 0] = (np.arange(32) * 8 - 128) * 8     # DC -> flat blocks of luma 0, 8, 16, ...
+    planes[1][:, 0] = (28 - 128) * 8
+    planes[2][:, 0] = (228 - 128) * 8
+    want = orc.backend_run(d, planes, QT)
+    assert np.array_equal(gpu.backend_run(helpers.to_gpu_desc(gpu, d), planes, QT), want)
+
+
+# ---- BASELINE.json sizes: stripes vs the oracle + size-independent properties -------------------
+
+BIG = {"c2_4096x4096_444": (4096, 4096, ((1, 1),) * 3), "c3_8192x8192_420": (8192, 8192, ((2, 2), (1, 1), (1, 1))),
+       "c4_4096x4096_422": (4096, 4096, ((2, 1), (1, 1), (1, 1))), "c1_512x512_gray": (512, 512, ((1, 1),))}
+
+
+@pytest.mark.parametrize("name", sorted(BIG))
+def test_baseline_sizes(gpu, name):
+    w, h, samp = BIG[name]
+    d = helpers.oracle_desc(w, h, samp)
+    planes = helpers.synth_planes(d, 0x5EED0000 + len(name))
+    gd = helpers.to_gpu_desc(gpu, d)
+    full = gpu.backend_run(gd, planes, QT)
+    # (1) MCU-row stripes (first, middle, last) against the oracle
+    band = d.max_v * 8
+    for m0 in sorted({0, d.nbmcuV // 2, d.nbmcuV - 1}):
+        want = orc.backend_run(d, planes, QT, mcu_rows=(m0, m0 + 1))
+        assert np.array_equal(full[m0 * band:(m0 + 1) * band], want[m0 * band:(m0 + 1) * band]), (name, m0)
+    # (2) stripe decomposition == whole frame (the multi-GPU sharding property): run the two halves
+    #     as independent frames and concatenate
+    half = d.nbmcuV // 2
+    parts = []
+    for (m0, m1) in ((0, half), (half, d.nbmcuV)):
+        sd = helpers.to_gpu_desc(gpu, d)
+        sd.nbmcuV = m1 - m0
+        sub = [planes[c][m0 * d.comp[c].vs * d.nbmcuH * d.comp[c].hs: m1 * d.comp[c].vs * d.nbmcuH * d.comp[c].hs] for c in range(d.nbcomp)]
+        parts.append(gpu.backend_run(sd, sub, QT))
+    assert np.array_equal(np.concatenate(parts), full)
+    # (3) idempotence / determinism: a second run gives the same bytes
+    assert sha(gpu.backend_run(gd, planes, QT)) == sha(full)
+
+
+def test_batch_equals_frame_by_frame(gpu):
+    """jpeggpu_backend_run_batch_device over N frames == N single-frame calls (C5's unit of work)."""
+    import torch
+    d = helpers.oracle_desc(1920, 1080, ((2, 2), (1, 1), (1, 1)))
+    gd = helpers.to_gpu_desc(gpu, d)
+    nf = 5
+    nb = [helpers.plane_shape(d, c)[0] for c in range(3)]
+    host = [pyoracle.synth_blocks(nb[c] * nf, 900 + c) for c in range(3)]
+    dev = [torch.from_numpy(a).cuda() for a in host]
+    rows, rb = gpu.raster_rows(gd), gpu.raster_row_bytes(gd)
+    out = torch.zeros(nf * rows * rb, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    gpu.backend_run_batch_device(gd, nf, [t.data_ptr() for t in dev], None, QT, out.data_ptr(), 0, 0, st.cuda_stream)
+    st.synchronize()
+    got = out.cpu().numpy().reshape(nf, rows, rb)
+    assert rows == 1088                                   # padded rows quirk, src/decoder_utils.c:68
+    for f in (0, 2, 4):
+        planes = [host[c][f * nb[c]:(f + 1) * nb[c]] for c in range(3)]
+        assert np.array_equal(got[f], gpu.backend_run(gd, planes, QT))
+    f = 3
+    planes = [host[c][f * nb[c]:(f + 1) * nb[c]] for c in range(3)]
+    want = orc.backend_run(d, planes, QT, mcu_rows=(10, 12))
+    assert np.array_equal(got[f][160:192], want[160:192])
