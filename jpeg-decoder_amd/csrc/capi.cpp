@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -100,7 +101,10 @@ void plan_backend(const jpeggpu_frame_desc_t *d, const jpeggpu_qtable_t *const q
    memset(&p, 0, sizeof p);
    uint32_t per_mcu = 0;
    for (int c = 0; c < d->nbcomp; c++) per_mcu += (uint32_t)d->comp[c].hs * d->comp[c].vs;
-   const uint32_t target_blocks = 384;
+   uint32_t target_blocks = 192;
+   if (const char *e = getenv("JPEGGPU_TARGET_BLOCKS")) target_blocks = (uint32_t)atoi(e);   // tuning knob
+   bool direct = true;
+   if (const char *e = getenv("JPEGGPU_DIRECT")) direct = atoi(e) != 0;
    uint32_t T = floor_pow2(target_blocks / per_mcu > 0 ? target_blocks / per_mcu : 1);
    uint32_t cap = ceil_pow2(d->nbmcuH);
    if (T > cap) T = cap;
@@ -125,7 +129,8 @@ void plan_backend(const jpeggpu_frame_desc_t *d, const jpeggpu_qtable_t *const q
    ld.tiles_per_row = (d->nbmcuH + T - 1) / T;
    ld.mcu_rows = d->nbmcuV;
    ld.threads = (p.B + 63) / 64 * 64;
-   ld.lds_bytes = (size_t)ld.threads * 128 + 512;
+   ld.direct = direct;
+   ld.lds_bytes = (size_t)ld.threads * (direct ? 64 : 128) + 512;
 }
 
 int run_device(const jpeggpu_frame_desc_t *d, uint32_t nframes, const void *const d_coef[3], const size_t cfs[3],

@@ -95,6 +95,37 @@ JM_HD uint32_t to_u8(float s) {
    return (uint32_t)(int)x;
 }
 
+// Eight samples of one raster row -> two packed words.  The +128 is an ordinary (round-to-nearest)
+// fp32 add as in the reference; clamp + truncation are one v_cvt_pk_u8_f32 per sample: that
+// instruction saturates to [0,255] and follows MODE.fp_round, so it is issued with the fp32
+// rounding mode switched to round-toward-zero (probed on gfx950 by tools/probe_round.hip).  The
+// whole mode window is a single asm statement, so no other fp32 instruction can be scheduled into it.
+JM_HD uint2 pack_row(const float (&u)[8]) {
+   uint2 w;
+#if defined(__HIP_DEVICE_COMPILE__)
+   float x0 = u[0] + 128.0f, x1 = u[1] + 128.0f, x2 = u[2] + 128.0f, x3 = u[3] + 128.0f;
+   float x4 = u[4] + 128.0f, x5 = u[5] + 128.0f, x6 = u[6] + 128.0f, x7 = u[7] + 128.0f;
+   asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+                "s_nop 1\n\t"
+                "v_cvt_pk_u8_f32 %0, %2, 0, 0\n\t"
+                "v_cvt_pk_u8_f32 %1, %6, 0, 0\n\t"
+                "v_cvt_pk_u8_f32 %0, %3, 1, %0\n\t"
+                "v_cvt_pk_u8_f32 %1, %7, 1, %1\n\t"
+                "v_cvt_pk_u8_f32 %0, %4, 2, %0\n\t"
+                "v_cvt_pk_u8_f32 %1, %8, 2, %1\n\t"
+                "v_cvt_pk_u8_f32 %0, %5, 3, %0\n\t"
+                "v_cvt_pk_u8_f32 %1, %9, 3, %1\n\t"
+                "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\t"
+                "s_nop 1"
+                : "=&v"(w.x), "=&v"(w.y)
+                : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(x6), "v"(x7));
+#else
+   w.x = to_u8(u[0]) | (to_u8(u[1]) << 8) | (to_u8(u[2]) << 16) | (to_u8(u[3]) << 24);
+   w.y = to_u8(u[4]) | (to_u8(u[5]) << 8) | (to_u8(u[6]) << 16) | (to_u8(u[7]) << 24);
+#endif
+   return w;
+}
+
 // 2-D transform of one block held as m[c][r] (column c, row r), idct_opt (src/idct_opt.c:93-117):
 // first along r for every column, then along c for every row.  Result packed as 8 raster rows of
 // 8 bytes: row[r] = {lo: columns 0..3, hi: columns 4..7}, byte c = sample (c, r).
@@ -107,8 +138,7 @@ JM_HD void idct_block(float (&m)[8][8], uint2 (&row)[8]) {
 #pragma unroll
       for (int c = 0; c < 8; c++) u[c] = m[c][r];
       idct8(u);
-      row[r].x = to_u8(u[0]) | (to_u8(u[1]) << 8) | (to_u8(u[2]) << 16) | (to_u8(u[3]) << 24);
-      row[r].y = to_u8(u[4]) | (to_u8(u[5]) << 8) | (to_u8(u[6]) << 16) | (to_u8(u[7]) << 24);
+      row[r] = pack_row(u);
    }
 }
 
@@ -125,14 +155,18 @@ JM_HD float dequant_to_float(int zz, uint32_t q) {
                      3,2,1,0,1,2,3,4, 5,6,7,7,6,5,4,3, 2,3,4,5,6,7,7,6, 5,4,5,6,7,7,6,7 }
 
 // iquant + izz + int16->float for one block: zw = the 64 zigzag int16 as 32 little-endian words,
-// qw = the table packed the same way.  m[col][row] as izz stores it (src/iqzz.c:23).
+// qw = the table packed the same way.  m[col][row] as izz stores it (src/iqzz.c:23).  The product
+// keeps its low 16 bits (src/iqzz.c:12 narrows to int16), which is exactly v_pk_mul_lo_u16.
+typedef unsigned short jm_us2 __attribute__((ext_vector_type(2)));
 JM_HD void dequant_izz(const uint32_t (&zw)[32], const uint32_t (&qw)[32], float (&m)[8][8]) {
    constexpr uint8_t ZR[64] = JM_ZZ_ROWS;
    constexpr uint8_t ZC[64] = JM_ZZ_COLS;
 #pragma unroll
    for (int i = 0; i < 32; i++) {
-      m[ZC[2 * i]][ZR[2 * i]] = dequant_to_float((int)(short)(zw[i] & 0xFFFF), qw[i] & 0xFFFF);
-      m[ZC[2 * i + 1]][ZR[2 * i + 1]] = dequant_to_float((int)zw[i] >> 16, qw[i] >> 16);
+      jm_us2 a = __builtin_bit_cast(jm_us2, zw[i]), b = __builtin_bit_cast(jm_us2, qw[i]);
+      jm_us2 pr = a * b;
+      m[ZC[2 * i]][ZR[2 * i]] = (float)(int)(short)pr.x;
+      m[ZC[2 * i + 1]][ZR[2 * i + 1]] = (float)(int)(short)pr.y;
    }
 }
 
@@ -155,6 +189,23 @@ JM_HD int clamp8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 JM_HD uint32_t ycc_to_rgb(int y, const ChromaOff &o) {
    int g = y + o.g - (o.fix & ((unsigned)(y - 94) < 72u));
    return (uint32_t)clamp8(y + o.r) | ((uint32_t)clamp8(g) << 8) | ((uint32_t)clamp8(y + o.b) << 16);
+}
+
+// Fast path used by the fused kernel: offsets without the per-sample pair test; the caller tests
+// whole words of chroma samples for the special pair with has_special_pair() and only then takes
+// the exact per-pixel form above.
+struct Off3 { int r, g, b; };
+JM_HD Off3 chroma_off3(int cb, int cr) {
+   Off3 o;
+   o.r = (91881 * cr + (100 - 91881 * 128)) >> 16;
+   o.b = (116130 * cb + (128 - 116130 * 128)) >> 16;
+   o.g = ((120 + 2886855 * 128 + 5990640 * 128) - 2886855 * cb - 5990640 * cr) >> 23;
+   return o;
+}
+// true iff some byte position holds cb == 28 and cr == 228 (zero-byte test on the xor words)
+JM_HD bool has_special_pair(uint32_t cbw, uint32_t crw) {
+   uint32_t t = (cbw ^ 0x1C1C1C1Cu) | (crw ^ 0xE4E4E4E4u);
+   return ((t - 0x01010101u) & ~t & 0x80808080u) != 0;
 }
 
 }  // namespace jpegmath

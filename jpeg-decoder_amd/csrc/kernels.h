@@ -32,7 +32,7 @@ struct BackendParams {
    uint32_t qt[4][32];             // quantisation tables, zigzag order, two uint16 per word
 };
 
-struct LaunchDims { uint32_t tiles_per_row, mcu_rows, frames, threads; size_t lds_bytes; };
+struct LaunchDims { uint32_t tiles_per_row, mcu_rows, frames, threads; size_t lds_bytes; bool direct; };
 
 hipError_t launch_backend(const BackendParams &p, const LaunchDims &d, hipStream_t s);
 

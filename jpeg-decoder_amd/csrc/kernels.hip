@@ -47,16 +47,17 @@ __device__ __forceinline__ void store_rgb_quad(uint8_t *dst, uint32_t w0, uint32
    }
 }
 
-template <int HFC, int VFC>   // chroma factors; 0 = generic path (any factors, any component)
+template <int HFC, int VFC, bool DIRECT>   // chroma factors; 0 = generic path (any factors, any component)
 __global__ void __launch_bounds__(512) backend_kernel(const BackendParams p) {
    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
    uint4 *stage = reinterpret_cast<uint4 *>(lds);
    const uint32_t tid = threadIdx.x, nt = blockDim.x;
    const uint32_t tile = blockIdx.x, m = blockIdx.y, frame = blockIdx.z;
-   uint32_t *qt_lds = reinterpret_cast<uint32_t *>(lds + (size_t)nt * 128);
+   uint32_t *qt_lds = reinterpret_cast<uint32_t *>(lds + (size_t)nt * (DIRECT ? 64 : 128));
 
    // ---- phase 0: tile coefficients -> LDS --------------------------------------------------
    if (p.apply_iquant && tid < 128) qt_lds[tid] = p.qt[tid >> 5][tid & 31];
+   if (!DIRECT)
    for (uint32_t j = tid; j < p.B * 8; j += nt) {
       uint32_t b = j >> 3, k = (j & 7) ^ ((b >> 1) & 7);
       uint32_t c, by, bxl;
@@ -82,12 +83,28 @@ __global__ void __launch_bounds__(512) backend_kernel(const BackendParams p) {
          decode_block(p, tid, c, by, bxl);
          const uint4 *q4 = reinterpret_cast<const uint4 *>(qt_lds + p.idq[c] * 32);
          uint32_t zw[32], qw[32];
+         uint4 v[8];
+         if (DIRECT) {
+            // each lane pulls its own 128-byte blocl16_t record: 8 x 16 B, one full cache line per lane
+            const uint32_t col = tile * p.bw[c] + bxl;
+            const uint4 *src = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(p.coef[c]) + (size_t)frame * p.coef_frame_stride[c] +
+                                                               (((size_t)m * p.vs[c] + by) * p.nbH[c] + col) * 128);
+            if (col < p.nbH[c]) {
+#pragma unroll
+               for (int k = 0; k < 8; k++) v[k] = src[k];
+            } else {
+#pragma unroll
+               for (int k = 0; k < 8; k++) v[k] = make_uint4(0, 0, 0, 0);
+            }
+         } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = stage[tid * 8 + (k ^ ((tid >> 1) & 7))];
+         }
 #pragma unroll
          for (int k = 0; k < 8; k++) {
-            uint4 v = stage[tid * 8 + (k ^ ((tid >> 1) & 7))];
             uint4 q = make_uint4(0x00010001u, 0x00010001u, 0x00010001u, 0x00010001u);
             if (p.apply_iquant) q = q4[k];
-            zw[4 * k] = v.x; zw[4 * k + 1] = v.y; zw[4 * k + 2] = v.z; zw[4 * k + 3] = v.w;
+            zw[4 * k] = v[k].x; zw[4 * k + 1] = v[k].y; zw[4 * k + 2] = v[k].z; zw[4 * k + 3] = v[k].w;
             qw[4 * k] = q.x; qw[4 * k + 1] = q.y; qw[4 * k + 2] = q.z; qw[4 * k + 3] = q.w;
          }
          dequant_izz(zw, qw, mtx);
@@ -125,31 +142,69 @@ __global__ void __launch_bounds__(512) backend_kernel(const BackendParams p) {
    }
    const uint32_t pitch1 = p.bw[1] * 8, pitch2 = p.bw[2] * 8;
    const uint8_t *pl0 = lds + p.plane_off[0], *pl1 = lds + p.plane_off[1], *pl2 = lds + p.plane_off[2];
-   for (uint32_t it = tid; it < nitems; it += nt) {
-      uint32_t y = (p.wq_shift < 32) ? (it >> p.wq_shift) : (it / wq), x = (it - y * wq) * 4;
-      if (x0 + x >= p.width) continue;
-      uint32_t n = min(4u, p.width - (x0 + x));
-      uint32_t px[4];
-      if constexpr (HFC != 0) {
-         // Y at full resolution, Cb and Cr share (HFC, VFC)
-         uint32_t yy = *reinterpret_cast<const uint32_t *>(pl0 + y * pitch0 + x);
-         uint32_t cy = y / VFC;
+   if constexpr (HFC != 0) {
+      // Y at full resolution, Cb and Cr share (HFC, VFC).  One item = 4 pixels wide x VFC rows, so
+      // every chroma sample's offsets are computed once for all the pixels that replicate it.
+      const uint32_t nit = wq * (p.tile_rows / VFC);
+      for (uint32_t it = tid; it < nit; it += nt) {
+         const uint32_t yi = (p.wq_shift < 32) ? (it >> p.wq_shift) : (it / wq), x = (it - yi * wq) * 4;
+         if (x0 + x >= p.width) continue;
+         const uint32_t n = min(4u, p.width - (x0 + x));
+         const uint32_t y = yi * VFC;
          uint32_t cbw, crw;
          if (HFC == 1) {
-            cbw = *reinterpret_cast<const uint32_t *>(pl1 + cy * pitch1 + x);
-            crw = *reinterpret_cast<const uint32_t *>(pl2 + cy * pitch2 + x);
+            cbw = *reinterpret_cast<const uint32_t *>(pl1 + yi * pitch1 + x);
+            crw = *reinterpret_cast<const uint32_t *>(pl2 + yi * pitch2 + x);
          } else {
-            cbw = *reinterpret_cast<const uint16_t *>(pl1 + cy * pitch1 + (x >> 1));
-            crw = *reinterpret_cast<const uint16_t *>(pl2 + cy * pitch2 + (x >> 1));
+            cbw = *reinterpret_cast<const uint16_t *>(pl1 + yi * pitch1 + (x >> 1));
+            crw = *reinterpret_cast<const uint16_t *>(pl2 + yi * pitch2 + (x >> 1));
+            cbw |= 0x01010000u;   // unused byte lanes can never look like the special pair
+         }
+         uint32_t yy[VFC];
+#pragma unroll
+         for (int v = 0; v < VFC; v++) yy[v] = *reinterpret_cast<const uint32_t *>(pl0 + (y + v) * pitch0 + x);
+         uint32_t w[VFC][3];
+         if (__builtin_expect(__any(has_special_pair(cbw, crw)), 0)) {
+            // exact per-pixel form (the y-dependent green offset of (cb,cr) = (28,228))
+#pragma unroll
+            for (int v = 0; v < VFC; v++) {
+               uint32_t px[4];
+#pragma unroll
+               for (int i = 0; i < 4; i++) {
+                  const int ci = (HFC == 1) ? i : (i >> 1);
+                  px[i] = ycc_to_rgb((yy[v] >> (8 * i)) & 0xFF, chroma_offsets((cbw >> (8 * ci)) & 0xFF, (crw >> (8 * ci)) & 0xFF));
+               }
+               w[v][0] = px[0] | (px[1] << 24); w[v][1] = (px[1] >> 8) | (px[2] << 16); w[v][2] = (px[2] >> 16) | (px[3] << 8);
+            }
+         } else {
+            Off3 o[4 / HFC];
+#pragma unroll
+            for (int ci = 0; ci < 4 / HFC; ci++) o[ci] = chroma_off3((cbw >> (8 * ci)) & 0xFF, (crw >> (8 * ci)) & 0xFF);
+#pragma unroll
+            for (int v = 0; v < VFC; v++) {
+               int r[4], g[4], b[4];
+#pragma unroll
+               for (int i = 0; i < 4; i++) {
+                  const int ci = (HFC == 1) ? i : (i >> 1);
+                  const int ys = (yy[v] >> (8 * i)) & 0xFF;
+                  r[i] = clamp8(ys + o[ci].r); g[i] = clamp8(ys + o[ci].g); b[i] = clamp8(ys + o[ci].b);
+               }
+               w[v][0] = r[0] | (g[0] << 8) | (b[0] << 16) | (r[1] << 24);
+               w[v][1] = g[1] | (b[1] << 8) | (r[2] << 16) | (g[2] << 24);
+               w[v][2] = b[2] | (r[3] << 8) | (g[3] << 16) | (b[3] << 24);
+            }
          }
 #pragma unroll
-         for (int i = 0; i < 4; i++) {
-            int ci = (HFC == 1) ? i : (i >> 1);
-            ChromaOff o = chroma_offsets((cbw >> (8 * ci)) & 0xFF, (crw >> (8 * ci)) & 0xFF);
-            px[i] = ycc_to_rgb((yy >> (8 * i)) & 0xFF, o);
-         }
-      } else {
-         // generic replicate upsampling, any integer factors (src/decoder_utils.c:72-80)
+         for (int v = 0; v < VFC; v++)
+            store_rgb_quad(out + (size_t)(y + v) * p.out_stride + (size_t)(x0 + x) * 3, w[v][0], w[v][1], w[v][2], n);
+      }
+   } else {
+      // generic replicate upsampling, any integer factors (src/decoder_utils.c:72-80)
+      for (uint32_t it = tid; it < nitems; it += nt) {
+         uint32_t y = (p.wq_shift < 32) ? (it >> p.wq_shift) : (it / wq), x = (it - y * wq) * 4;
+         if (x0 + x >= p.width) continue;
+         uint32_t n = min(4u, p.width - (x0 + x));
+         uint32_t px[4];
 #pragma unroll
          for (int i = 0; i < 4; i++) {
             uint32_t xx = x + i;
@@ -158,23 +213,23 @@ __global__ void __launch_bounds__(512) backend_kernel(const BackendParams p) {
             int s2 = pl2[(y / p.vf[2]) * pitch2 + xx / p.hf[2]];
             px[i] = ycc_to_rgb(s0, chroma_offsets(s1, s2));
          }
+         uint32_t w0 = px[0] | (px[1] << 24);
+         uint32_t w1 = (px[1] >> 8) | (px[2] << 16);
+         uint32_t w2 = (px[2] >> 16) | (px[3] << 8);
+         store_rgb_quad(out + (size_t)y * p.out_stride + (size_t)(x0 + x) * 3, w0, w1, w2, n);
       }
-      uint32_t w0 = px[0] | (px[1] << 24);
-      uint32_t w1 = (px[1] >> 8) | (px[2] << 16);
-      uint32_t w2 = (px[2] >> 16) | (px[3] << 8);
-      store_rgb_quad(out + (size_t)y * p.out_stride + (size_t)(x0 + x) * 3, w0, w1, w2, n);
    }
 }
 
 hipError_t launch_backend(const BackendParams &p, const LaunchDims &d, hipStream_t s) {
    dim3 grid(d.tiles_per_row, d.mcu_rows, d.frames), block(d.threads);
-   void (*k)(const BackendParams) = backend_kernel<0, 0>;
+   void (*k)(const BackendParams) = d.direct ? backend_kernel<0, 0, true> : backend_kernel<0, 0, false>;
    if (p.nbcomp == 3 && p.hf[0] == 1 && p.vf[0] == 1 && p.hf[1] == p.hf[2] && p.vf[1] == p.vf[2]) {
       uint32_t h = p.hf[1], v = p.vf[1];
-      if (h == 1 && v == 1) k = backend_kernel<1, 1>;
-      else if (h == 2 && v == 1) k = backend_kernel<2, 1>;
-      else if (h == 2 && v == 2) k = backend_kernel<2, 2>;
-      else if (h == 1 && v == 2) k = backend_kernel<1, 2>;
+      if (h == 1 && v == 1) k = d.direct ? backend_kernel<1, 1, true> : backend_kernel<1, 1, false>;
+      else if (h == 2 && v == 1) k = d.direct ? backend_kernel<2, 1, true> : backend_kernel<2, 1, false>;
+      else if (h == 2 && v == 2) k = d.direct ? backend_kernel<2, 2, true> : backend_kernel<2, 2, false>;
+      else if (h == 1 && v == 2) k = d.direct ? backend_kernel<1, 2, true> : backend_kernel<1, 2, false>;
    }
    if (d.lds_bytes > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d.lds_bytes);
