@@ -37,7 +37,7 @@ class FrameDesc(C.Structure):
                 ("nbmcuH", C.c_uint32), ("nbmcuV", C.c_uint32), ("comp", Component * 3)]
 
 
-lib_path = os.path.join(os.path.dirname(os.path.realpath(__file__)), "libjpeggpu.so")
+lib_path = os.environ.get("JPEGGPU_LIB") or os.path.join(os.path.dirname(os.path.realpath(__file__)), "libjpeggpu.so")
 if not os.path.exists(lib_path):
     raise ImportError(f"{lib_path} is missing: build it with `make -C jpeg-decoder_amd/csrc` "
                       "(or __graft_entry__.build()); there is no CPU fallback")

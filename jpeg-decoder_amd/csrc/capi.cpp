@@ -93,27 +93,24 @@ int validate(const jpeggpu_frame_desc_t *d, const jpeggpu_qtable_t *const qt[4])
    return 0;
 }
 
-uint32_t floor_pow2(uint32_t v) { uint32_t p = 1; while (p * 2 <= v) p *= 2; return p; }
-uint32_t ceil_pow2(uint32_t v) { uint32_t p = 1; while (p < v) p *= 2; return p; }
 
 // Tile planning: T MCUs per workgroup, one thread per block.
 void plan_backend(const jpeggpu_frame_desc_t *d, const jpeggpu_qtable_t *const qt[4], BackendParams &p, LaunchDims &ld) {
    memset(&p, 0, sizeof p);
    uint32_t per_mcu = 0;
    for (int c = 0; c < d->nbcomp; c++) per_mcu += (uint32_t)d->comp[c].hs * d->comp[c].vs;
-   uint32_t target_blocks = 192;
+   uint32_t target_blocks = 256;
    if (const char *e = getenv("JPEGGPU_TARGET_BLOCKS")) target_blocks = (uint32_t)atoi(e);   // tuning knob
-   bool direct = true;
-   if (const char *e = getenv("JPEGGPU_DIRECT")) direct = atoi(e) != 0;
-   uint32_t T = floor_pow2(target_blocks / per_mcu > 0 ? target_blocks / per_mcu : 1);
-   uint32_t cap = ceil_pow2(d->nbmcuH);
-   if (T > cap) T = cap;
+   if (target_blocks < 48) target_blocks = 48;          // one MCU can hold 3 * 4*4 blocks
+   if (target_blocks > 256) target_blocks = 256;        // __launch_bounds__(256)
+   // T MCUs per tile: the largest power of two that fits the block budget (4:4:4 -> 64 MCUs = 192
+   // blocks, 4:2:0 -> 32 = 192, 4:2:2 -> 64 = 256, gray -> 256), never more than the frame is wide
+   uint32_t T = 1;
+   while (T * 2 * per_mcu <= target_blocks) T *= 2;
+   if (T > d->nbmcuH) T = d->nbmcuH;
    p.T = T; p.B = T * per_mcu;
    p.nbcomp = d->nbcomp; p.apply_iquant = d->apply_iquant; p.width = d->width;
    p.tile_w = T * d->max_h * 8; p.tile_rows = (uint32_t)d->max_v * 8;
-   uint32_t wq = p.tile_w / 4;
-   p.wq_shift = 32;
-   if ((wq & (wq - 1)) == 0) { p.wq_shift = 0; while ((1u << p.wq_shift) < wq) p.wq_shift++; }
    uint32_t boff = 0, poff = 0;
    for (int c = 0; c < d->nbcomp; c++) {
       const jpeggpu_component_t &k = d->comp[c];
@@ -128,9 +125,8 @@ void plan_backend(const jpeggpu_frame_desc_t *d, const jpeggpu_qtable_t *const q
          if (qt[i]) pack_qtable(qt[i], p.qt[i]);
    ld.tiles_per_row = (d->nbmcuH + T - 1) / T;
    ld.mcu_rows = d->nbmcuV;
-   ld.threads = (p.B + 63) / 64 * 64;
-   ld.direct = direct;
-   ld.lds_bytes = (size_t)ld.threads * (direct ? 64 : 128) + 512;
+   ld.threads = (p.B + 63) / 64 * 64;                 // one thread per block
+   ld.lds_bytes = (size_t)ld.threads * 64 + 512;
 }
 
 int run_device(const jpeggpu_frame_desc_t *d, uint32_t nframes, const void *const d_coef[3], const size_t cfs[3],

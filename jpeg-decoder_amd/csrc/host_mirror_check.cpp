@@ -24,9 +24,13 @@ static size_t check_blocks(size_t n, uint64_t seed, int kind, const jpeggpu_qtab
       oracle_izz(z.data, sq.data);
       oracle_idct_opt(sq.data, want.data);
       uint32_t zw[32]; memcpy(zw, in[b].data, 128);
-      float m[8][8]; uint2 rows[8];
+      float m[8][8]; uint2 rows[8], rows2[8];
       dequant_izz(zw, qw, m);
       idct_block(m, rows);
+      f32x2 p1[4][8];
+      dequant_izz_pk(zw, qw, p1);           // the packed form the fused kernel uses
+      idct_block_pk(p1, rows2);
+      if (memcmp(rows, rows2, sizeof rows)) { bad++; continue; }
       for (int r = 0; r < 8; r++)
          for (int c = 0; c < 8; c++) {
             uint8_t got = (uint8_t)(((c < 4 ? rows[r].x : rows[r].y) >> (8 * (c & 3))) & 0xFF);
@@ -53,6 +57,10 @@ int main(int argc, char **argv) {
             oracle_ycc2rgb_pixel((uint8_t)y, (uint8_t)cb, (uint8_t)cr, want);
             uint32_t v = ycc_to_rgb(y, chroma_offsets(cb, cr));
             cbad += (v != ((uint32_t)want[0] | ((uint32_t)want[1] << 8) | ((uint32_t)want[2] << 16)));
+            if (!(cb == 28 && cr == 228)) {   // the fused kernel's fast path (everything but the special pair)
+               Off3 o = chroma_off3(cb - 128, cr - 128);
+               cbad += (clamp8(y + o.r) != want[0]) + (clamp8(y + o.g) != want[1]) + (clamp8(y + o.b) != want[2]);
+            }
          }
    printf("host mirror ycc2rgb: 2^24 inputs, %zu differing\n", cbad);
    bad += cbad;

@@ -41,15 +41,22 @@ namespace jpegmath {
 #define JM_SH8 0x1.6a09e6p-2f    // hi(SQRT_8) / 8
 #define JM_SL8 0x1.9fcef4p-28f   // lo(SQRT_8) / 8
 
+// Arithmetic is written once for T = float (one transform) and T = f32x2 (two independent
+// transforms side by side, which the compiler lowers to v_pk_add_f32 / v_pk_mul_f32 /
+// v_pk_fma_f32: the same IEEE operations per element, two per instruction).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+JM_HD float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+JM_HD f32x2 fma_t(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 // (float)((double)x * C) or (float)((double)x / C') as one multiply and one fma.
-JM_HD float mul_hl(float x, float hi, float lo) { return __builtin_fmaf(x, hi, x * lo); }
+template <typename T> JM_HD T mul_hl(T x, float hi, float lo) { return fma_t(x, (T)hi, x * (T)lo); }
 
 // One 8-point inverse transform, in place: idct_opt_1D (src/idct_opt.c:56-81).
 // v[] in natural coefficient order on entry, sample order on exit.
-JM_HD void idct8(float (&v)[8]) {
+template <typename T> JM_HD void idct8(T (&v)[8]) {
    // reorder (:49-54)
-   float t0 = v[0], t1 = v[4], t2 = v[2], t3 = v[6], t4 = v[7], t5 = v[3], t6 = v[5], t7 = v[1];
-   float a, b;
+   T t0 = v[0], t1 = v[4], t2 = v[2], t3 = v[6], t4 = v[7], t5 = v[3], t6 = v[5], t7 = v[1];
+   T a, b;
    // stage 4 inverse (:58-61); pending scale of t4..t7 becomes 2^-1
    a = t7 + t4; b = t7 - t4; t7 = a; t4 = b;
    t5 = mul_hl(t5, JM_RH2, JM_RL2);
@@ -57,9 +64,9 @@ JM_HD void idct8(float (&v)[8]) {
    // stage 3 inverse (:62-66); t0..t3 -> 2^-1, t4..t7 -> 2^-2
    a = t0 + t1; b = t0 - t1; t0 = a; t1 = b;
    {
-      float x = mul_hl(t2, JM_KH2, JM_KL2), y = mul_hl(t3, JM_KH2, JM_KL2);   // 2*(t/k)
-      t2 = x * JM_C6 - y * JM_S6;
-      t3 = y * JM_C6 + x * JM_S6;
+      T x = mul_hl(t2, JM_KH2, JM_KL2), y = mul_hl(t3, JM_KH2, JM_KL2);   // 2*(t/k)
+      t2 = x * (T)JM_C6 - y * (T)JM_S6;
+      t3 = y * (T)JM_C6 + x * (T)JM_S6;
    }
    a = t4 + t6; b = t4 - t6; t4 = a; t6 = b;
    a = t7 + t5; b = t7 - t5; t7 = a; t5 = b;
@@ -67,14 +74,14 @@ JM_HD void idct8(float (&v)[8]) {
    a = t0 + t3; b = t0 - t3; t0 = a; t3 = b;
    a = t1 + t2; b = t1 - t2; t1 = a; t2 = b;
    {
-      float x = t4, y = t7;
-      t4 = x * JM_C3 - y * JM_S3;
-      t7 = y * JM_C3 + x * JM_S3;
+      T x = t4, y = t7;
+      t4 = x * (T)JM_C3 - y * (T)JM_S3;
+      t7 = y * (T)JM_C3 + x * (T)JM_S3;
    }
    {
-      float x = t5, y = t6;
-      t5 = x * JM_C1 - y * JM_S1;
-      t6 = y * JM_C1 + x * JM_S1;
+      T x = t5, y = t6;
+      t5 = x * (T)JM_C1 - y * (T)JM_S1;
+      t6 = y * (T)JM_C1 + x * (T)JM_S1;
    }
    // stage 1 inverse (:72-76); everything -> 2^-3
    a = t0 + t7; b = t0 - t7; t0 = a; t7 = b;
@@ -142,6 +149,50 @@ JM_HD void idct_block(float (&m)[8][8], uint2 (&row)[8]) {
    }
 }
 
+// Same transform with two columns (pass 1) / two rows (pass 2) per packed instruction.
+// p1[cp][r] = { sample(col 2cp, row r), sample(col 2cp+1, row r) }.
+JM_HD void idct_block_pk(f32x2 (&p1)[4][8], uint2 (&row)[8]) {
+#pragma unroll
+   for (int cp = 0; cp < 4; cp++) idct8(p1[cp]);
+#pragma unroll
+   for (int rp = 0; rp < 4; rp++) {
+      f32x2 u[8];
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+         const f32x2 lo = p1[c >> 1][2 * rp], hi = p1[c >> 1][2 * rp + 1];
+         u[c] = (c & 1) ? f32x2{lo.y, hi.y} : f32x2{lo.x, hi.x};
+      }
+      idct8(u);
+      float a[8], b[8];
+#pragma unroll
+      for (int c = 0; c < 8; c++) { a[c] = u[c].x; b[c] = u[c].y; }
+      row[2 * rp] = pack_row(a);
+      row[2 * rp + 1] = pack_row(b);
+   }
+}
+// Hybrid: pass 1 packed (the column pairs come straight out of the dequantiser, no shuffles), pass 2
+// one row at a time on the halves of the pair registers (no 2x2 transposes).
+JM_HD void idct_block_hy(f32x2 (&p1)[4][8], uint2 (&row)[8]) {
+#pragma unroll
+   for (int cp = 0; cp < 4; cp++) idct8(p1[cp]);
+#pragma unroll
+   for (int r = 0; r < 8; r++) {
+      float u[8];
+#pragma unroll
+      for (int c = 0; c < 8; c++) u[c] = (c & 1) ? p1[c >> 1][r].y : p1[c >> 1][r].x;
+      idct8(u);
+      row[r] = pack_row(u);
+   }
+}
+JM_HD void idct_block_pk(float (&m)[8][8], uint2 (&row)[8]) {
+   f32x2 p1[4][8];
+#pragma unroll
+   for (int cp = 0; cp < 4; cp++)
+#pragma unroll
+      for (int r = 0; r < 8; r++) p1[cp][r] = f32x2{m[2 * cp][r], m[2 * cp + 1][r]};
+   idct_block_pk(p1, row);
+}
+
 // iquant (src/iqzz.c:12): product narrowed to int16 (wraps), then the int16 -> float conversion of
 // src/idct_opt.c:97.
 JM_HD float dequant_to_float(int zz, uint32_t q) {
@@ -170,6 +221,20 @@ JM_HD void dequant_izz(const uint32_t (&zw)[32], const uint32_t (&qw)[32], float
    }
 }
 
+// dequant_izz straight into the column-pair layout of idct_block_pk.
+JM_HD void dequant_izz_pk(const uint32_t (&zw)[32], const uint32_t (&qw)[32], f32x2 (&p1)[4][8]) {
+   constexpr uint8_t ZR[64] = JM_ZZ_ROWS;
+   constexpr uint8_t ZC[64] = JM_ZZ_COLS;
+#pragma unroll
+   for (int i = 0; i < 32; i++) {
+      jm_us2 a = __builtin_bit_cast(jm_us2, zw[i]), b = __builtin_bit_cast(jm_us2, qw[i]);
+      jm_us2 pr = a * b;
+      const float f0 = (float)(int)(short)pr.x, f1 = (float)(int)(short)pr.y;
+      if (ZC[2 * i] & 1) p1[ZC[2 * i] >> 1][ZR[2 * i]].y = f0; else p1[ZC[2 * i] >> 1][ZR[2 * i]].x = f0;
+      if (ZC[2 * i + 1] & 1) p1[ZC[2 * i + 1] >> 1][ZR[2 * i + 1]].y = f1; else p1[ZC[2 * i + 1] >> 1][ZR[2 * i + 1]].x = f1;
+   }
+}
+
 // ---- colour conversion, src/ycc2rgb.c:18-22 -------------------------------------------------
 // r = clamp8(y + ((91881*(cr-128) + 100) >> 16)), b = clamp8(y + ((116130*(cb-128) + 128) >> 16)),
 // g = clamp8(y + ((120 - 2886855*(cb-128) - 5990640*(cr-128)) >> 23) - fix) where fix = 1 only
@@ -195,11 +260,20 @@ JM_HD uint32_t ycc_to_rgb(int y, const ChromaOff &o) {
 // whole words of chroma samples for the special pair with has_special_pair() and only then takes
 // the exact per-pixel form above.
 struct Off3 { int r, g, b; };
-JM_HD Off3 chroma_off3(int cb, int cr) {
+// du = cb - 128, dv = cr - 128 (callers get them for free as sign-extended bytes of word ^ 0x80808080).
+// With the centred form the R and B biases may be 0 (both lie inside the admissible intervals
+// printed by tools/explore_color.c), so each is one 24-bit multiply whose upper half is the offset.
+JM_HD Off3 chroma_off3(int du, int dv) {
    Off3 o;
-   o.r = (91881 * cr + (100 - 91881 * 128)) >> 16;
-   o.b = (116130 * cb + (128 - 116130 * 128)) >> 16;
-   o.g = ((120 + 2886855 * 128 + 5990640 * 128) - 2886855 * cb - 5990640 * cr) >> 23;
+#if defined(__HIP_DEVICE_COMPILE__)
+   o.r = __mul24(dv, 91881) >> 16;
+   o.b = __mul24(du, 116130) >> 16;
+   o.g = (__mul24(dv, -5990640) + __mul24(du, -2886855) + 120) >> 23;
+#else
+   o.r = (91881 * dv) >> 16;
+   o.b = (116130 * du) >> 16;
+   o.g = (120 - 2886855 * du - 5990640 * dv) >> 23;
+#endif
    return o;
 }
 // true iff some byte position holds cb == 28 and cr == 228 (zero-byte test on the xor words)

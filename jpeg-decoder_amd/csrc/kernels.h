@@ -21,7 +21,6 @@ struct BackendParams {
    uint32_t B;                     // blocks per tile = T * sum(hs*vs)
    uint32_t tile_w;                // pixels per tile row  = T * max_h * 8
    uint32_t tile_rows;             // raster rows per tile = max_v * 8
-   uint32_t wq_shift;              // log2(tile_w/4) when that is a power of two, else 32
    uint32_t nbH[3];                // blocks per plane row (nbmcuH*hs)
    uint32_t vs[3];                 // block rows per MCU row
    uint32_t bw[3];                 // blocks per tile row of component c = T*hs
@@ -32,7 +31,7 @@ struct BackendParams {
    uint32_t qt[4][32];             // quantisation tables, zigzag order, two uint16 per word
 };
 
-struct LaunchDims { uint32_t tiles_per_row, mcu_rows, frames, threads; size_t lds_bytes; bool direct; };
+struct LaunchDims { uint32_t tiles_per_row, mcu_rows, frames, threads; size_t lds_bytes; };
 
 hipError_t launch_backend(const BackendParams &p, const LaunchDims &d, hipStream_t s);
 

@@ -26,16 +26,35 @@ using namespace jpegmath;
 
 struct __attribute__((packed, aligned(4))) rgb4_t { uint32_t a, b, c; };
 
-__device__ __forceinline__ void decode_block(const BackendParams &p, uint32_t b, uint32_t &c, uint32_t &by, uint32_t &bxl) {
-   c = (p.nbcomp == 3) ? (uint32_t)(b >= p.boff[1]) + (uint32_t)(b >= p.boff[2]) : 0u;
-   uint32_t r = b - p.boff[c];
-   uint32_t w = p.bw[c];
-   by = (uint32_t)(r >= w) + (uint32_t)(r >= 2 * w) + (uint32_t)(r >= 3 * w);
-   bxl = r - by * w;
+// Per-thread view of the component a tile-block belongs to.  All fields are selected from scalar
+// kernel arguments with v_cndmask (no per-lane memory loads).
+struct BlockCtx {
+   uint32_t c, by, bxl, bw, nbH, vs, idq, plane_off;
+   const uint8_t *coef; uint64_t frame_stride;
+};
+template <typename T> __device__ __forceinline__ T sel3(uint32_t c, T a0, T a1, T a2) { return c == 0 ? a0 : (c == 1 ? a1 : a2); }
+
+__device__ __forceinline__ BlockCtx decode_block(const BackendParams &p, uint32_t b) {
+   BlockCtx k;
+   k.c = (p.nbcomp == 3) ? (uint32_t)(b >= p.boff[1]) + (uint32_t)(b >= p.boff[2]) : 0u;
+   k.bw = sel3(k.c, p.bw[0], p.bw[1], p.bw[2]);
+   k.nbH = sel3(k.c, p.nbH[0], p.nbH[1], p.nbH[2]);
+   k.vs = sel3(k.c, p.vs[0], p.vs[1], p.vs[2]);
+   k.idq = sel3(k.c, p.idq[0], p.idq[1], p.idq[2]);
+   k.plane_off = sel3(k.c, p.plane_off[0], p.plane_off[1], p.plane_off[2]);
+   k.coef = static_cast<const uint8_t *>(sel3(k.c, p.coef[0], p.coef[1], p.coef[2]));
+   k.frame_stride = sel3(k.c, p.coef_frame_stride[0], p.coef_frame_stride[1], p.coef_frame_stride[2]);
+   const uint32_t r = b - sel3(k.c, p.boff[0], p.boff[1], p.boff[2]);
+   k.by = (uint32_t)(r >= k.bw) + (uint32_t)(r >= 2 * k.bw) + (uint32_t)(r >= 3 * k.bw);
+   k.bxl = r - k.by * k.bw;
+   return k;
 }
 
 // store up to 4 pixels (12 bytes) whose first byte is dst; n = number of valid pixels (1..4)
 __device__ __forceinline__ void store_rgb_quad(uint8_t *dst, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t n) {
+#if defined(JM_DIAG_NOSTORE)
+   if ((w0 ^ w1 ^ w2) != 0x12345678u) return;
+#endif
    if (n == 4 && ((uintptr_t)dst & 3) == 0) {
       rgb4_t v = { w0, w1, w2 };
       *reinterpret_cast<rgb4_t *>(dst) = v;
@@ -47,90 +66,91 @@ __device__ __forceinline__ void store_rgb_quad(uint8_t *dst, uint32_t w0, uint32
    }
 }
 
-template <int HFC, int VFC, bool DIRECT>   // chroma factors; 0 = generic path (any factors, any component)
-__global__ void __launch_bounds__(512) backend_kernel(const BackendParams p) {
+template <int HFC, int VFC>   // chroma factors; 0 = generic path (any factors, any component)
+__global__ void __launch_bounds__(256) backend_kernel(const BackendParams p) {
    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-   uint4 *stage = reinterpret_cast<uint4 *>(lds);
+   // One workgroup per tile of T MCUs, one thread per 8x8 block (B = blockDim.x rounded down).
    const uint32_t tid = threadIdx.x, nt = blockDim.x;
    const uint32_t tile = blockIdx.x, m = blockIdx.y, frame = blockIdx.z;
-   uint32_t *qt_lds = reinterpret_cast<uint32_t *>(lds + (size_t)nt * (DIRECT ? 64 : 128));
+   uint32_t *qt_lds = reinterpret_cast<uint32_t *>(lds + (size_t)nt * 64);
 
-   // ---- phase 0: tile coefficients -> LDS --------------------------------------------------
-   if (p.apply_iquant && tid < 128) qt_lds[tid] = p.qt[tid >> 5][tid & 31];
-   if (!DIRECT)
-   for (uint32_t j = tid; j < p.B * 8; j += nt) {
-      uint32_t b = j >> 3, k = (j & 7) ^ ((b >> 1) & 7);
-      uint32_t c, by, bxl;
-      decode_block(p, b, c, by, bxl);
-      uint32_t col = tile * p.bw[c] + bxl;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (col < p.nbH[c]) {
-         const uint8_t *src = static_cast<const uint8_t *>(p.coef[c]) + (size_t)frame * p.coef_frame_stride[c] +
-                              (((size_t)m * p.vs[c] + by) * p.nbH[c] + col) * 128 + k * 16;
-         v = *reinterpret_cast<const uint4 *>(src);
-      }
-      stage[j] = v;
-   }
-   __syncthreads();
-
-   // ---- phase 1: one block per thread -------------------------------------------------------
+   // ---- phase 1: one block per thread ----------------------------------------------------------
+   // each lane pulls its own 128-byte blocl16_t record straight into registers: 8 x 16 B, one full
+   // cache line per lane (measured 1.3x faster than staging the tile through LDS with coalesced
+   // loads, and it leaves the LDS to the u8 planes alone, so twice as many tiles are resident)
    const bool active = tid < p.B;
-   uint32_t c = 0, by = 0, bxl = 0;
-   uint2 rows[8];
+   const BlockCtx k = decode_block(p, active ? tid : 0);
+   uint4 v[8];
    {
-      float mtx[8][8];
-      if (active) {
-         decode_block(p, tid, c, by, bxl);
-         const uint4 *q4 = reinterpret_cast<const uint4 *>(qt_lds + p.idq[c] * 32);
-         uint32_t zw[32], qw[32];
-         uint4 v[8];
-         if (DIRECT) {
-            // each lane pulls its own 128-byte blocl16_t record: 8 x 16 B, one full cache line per lane
-            const uint32_t col = tile * p.bw[c] + bxl;
-            const uint4 *src = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(p.coef[c]) + (size_t)frame * p.coef_frame_stride[c] +
-                                                               (((size_t)m * p.vs[c] + by) * p.nbH[c] + col) * 128);
-            if (col < p.nbH[c]) {
+      const uint32_t col = tile * k.bw + k.bxl;
+      const uint4 *src = reinterpret_cast<const uint4 *>(k.coef + (size_t)frame * k.frame_stride +
+                                                         (((size_t)m * k.vs + k.by) * k.nbH + col) * 128);
+#if defined(JM_DIAG_NOLOAD)
+      if (false) {
+#else
+      if (active && col < k.nbH) {
+#endif
 #pragma unroll
-               for (int k = 0; k < 8; k++) v[k] = src[k];
-            } else {
+         for (int i = 0; i < 8; i++) v[i] = src[i];
+      } else {
 #pragma unroll
-               for (int k = 0; k < 8; k++) v[k] = make_uint4(0, 0, 0, 0);
-            }
-         } else {
-#pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = stage[tid * 8 + (k ^ ((tid >> 1) & 7))];
-         }
-#pragma unroll
-         for (int k = 0; k < 8; k++) {
-            uint4 q = make_uint4(0x00010001u, 0x00010001u, 0x00010001u, 0x00010001u);
-            if (p.apply_iquant) q = q4[k];
-            zw[4 * k] = v[k].x; zw[4 * k + 1] = v[k].y; zw[4 * k + 2] = v[k].z; zw[4 * k + 3] = v[k].w;
-            qw[4 * k] = q.x; qw[4 * k + 1] = q.y; qw[4 * k + 2] = q.z; qw[4 * k + 3] = q.w;
-         }
-         dequant_izz(zw, qw, mtx);
+         for (int i = 0; i < 8; i++) v[i] = make_uint4(0, 0, 0, 0);
       }
-      __syncthreads();   // staging area is dead from here on; planes alias it
-      if (active) idct_block(mtx, rows);
    }
+   if (p.apply_iquant && tid < 128) qt_lds[tid] = p.qt[tid >> 5][tid & 31];
+   if (p.apply_iquant && nt < 128) qt_lds[tid + 64] = p.qt[(tid >> 5) + 2][tid & 31];   // nt == 64
+   __syncthreads();
    if (active) {
-      uint8_t *plane = lds + p.plane_off[c] + (size_t)(by * 8) * (p.bw[c] * 8) + bxl * 8;
+      uint2 rows[8];
+      {
+         f32x2 mtx[4][8];
+         const uint4 *q4 = reinterpret_cast<const uint4 *>(qt_lds + k.idq * 32);
+         uint32_t zw[32], qw[32];
 #pragma unroll
-      for (int r = 0; r < 8; r++) *reinterpret_cast<uint2 *>(plane + (size_t)r * (p.bw[c] * 8)) = rows[r];
+         for (int i = 0; i < 8; i++) {
+            uint4 q = make_uint4(0x00010001u, 0x00010001u, 0x00010001u, 0x00010001u);
+            if (p.apply_iquant) q = q4[i];
+            zw[4 * i] = v[i].x; zw[4 * i + 1] = v[i].y; zw[4 * i + 2] = v[i].z; zw[4 * i + 3] = v[i].w;
+            qw[4 * i] = q.x; qw[4 * i + 1] = q.y; qw[4 * i + 2] = q.z; qw[4 * i + 3] = q.w;
+         }
+         dequant_izz_pk(zw, qw, mtx);
+#if defined(JM_DIAG_NOIDCT)
+#pragma unroll
+         for (int r = 0; r < 8; r++) { float u[8];
+#pragma unroll
+            for (int c2 = 0; c2 < 8; c2++) u[c2] = (c2 & 1) ? mtx[c2 >> 1][r].y : mtx[c2 >> 1][r].x;
+            rows[r] = pack_row(u); }
+#else
+         idct_block_hy(mtx, rows);
+#endif
+      }
+      const uint32_t pitch = k.bw * 8;
+      uint8_t *plane = lds + k.plane_off + (k.by * 8) * pitch + k.bxl * 8;
+#pragma unroll
+      for (int r = 0; r < 8; r++) *reinterpret_cast<uint2 *>(plane + r * pitch) = rows[r];
    }
    __syncthreads();
 
+#if defined(JM_DIAG_NOPHASE2)
+   if (p.width != 12345) return;
+#endif
    // ---- phase 2: upsample + colour convert + store ------------------------------------------
    const uint32_t x0 = tile * p.tile_w;
    if (x0 >= p.width) return;
    const uint32_t wq = p.tile_w >> 2;                       // quads per tile row
    const uint32_t nitems = wq * p.tile_rows;
+   // item -> (row, quad) without a division per item: one division up front, then a running pair
+   uint32_t iy = tid / wq, ix = tid - iy * wq;
+   const uint32_t dy = nt / wq, dx = nt - dy * wq;
    uint8_t *out = static_cast<uint8_t *>(p.out) + (size_t)frame * p.out_frame_stride +
                   (size_t)m * p.tile_rows * p.out_stride;
    const uint32_t pitch0 = p.bw[0] * 8;
    if (p.nbcomp == 1) {
       // save_mcu_ligne_bw (src/decoder_utils.c:48-63): straight copy of the luma plane
       for (uint32_t it = tid; it < nitems; it += nt) {
-         uint32_t y = (p.wq_shift < 32) ? (it >> p.wq_shift) : (it / wq), x = (it - y * wq) * 4;
+         const uint32_t y = iy, x = ix * 4;
+         iy += dy; ix += dx;
+         if (ix >= wq) { ix -= wq; iy++; }
          if (x0 + x >= p.width) continue;
          uint32_t n = min(4u, p.width - (x0 + x));
          uint32_t v = *reinterpret_cast<const uint32_t *>(lds + p.plane_off[0] + y * pitch0 + x);
@@ -147,7 +167,9 @@ __global__ void __launch_bounds__(512) backend_kernel(const BackendParams p) {
       // every chroma sample's offsets are computed once for all the pixels that replicate it.
       const uint32_t nit = wq * (p.tile_rows / VFC);
       for (uint32_t it = tid; it < nit; it += nt) {
-         const uint32_t yi = (p.wq_shift < 32) ? (it >> p.wq_shift) : (it / wq), x = (it - yi * wq) * 4;
+         const uint32_t yi = iy, x = ix * 4;
+         iy += dy; ix += dx;
+         if (ix >= wq) { ix -= wq; iy++; }
          if (x0 + x >= p.width) continue;
          const uint32_t n = min(4u, p.width - (x0 + x));
          const uint32_t y = yi * VFC;
@@ -178,8 +200,9 @@ __global__ void __launch_bounds__(512) backend_kernel(const BackendParams p) {
             }
          } else {
             Off3 o[4 / HFC];
+            const uint32_t cbs = cbw ^ 0x80808080u, crs = crw ^ 0x80808080u;   // bytes become cb-128, cr-128 (int8)
 #pragma unroll
-            for (int ci = 0; ci < 4 / HFC; ci++) o[ci] = chroma_off3((cbw >> (8 * ci)) & 0xFF, (crw >> (8 * ci)) & 0xFF);
+            for (int ci = 0; ci < 4 / HFC; ci++) o[ci] = chroma_off3((int)(int8_t)(cbs >> (8 * ci)), (int)(int8_t)(crs >> (8 * ci)));
 #pragma unroll
             for (int v = 0; v < VFC; v++) {
                int r[4], g[4], b[4];
@@ -201,7 +224,9 @@ __global__ void __launch_bounds__(512) backend_kernel(const BackendParams p) {
    } else {
       // generic replicate upsampling, any integer factors (src/decoder_utils.c:72-80)
       for (uint32_t it = tid; it < nitems; it += nt) {
-         uint32_t y = (p.wq_shift < 32) ? (it >> p.wq_shift) : (it / wq), x = (it - y * wq) * 4;
+         const uint32_t y = iy, x = ix * 4;
+         iy += dy; ix += dx;
+         if (ix >= wq) { ix -= wq; iy++; }
          if (x0 + x >= p.width) continue;
          uint32_t n = min(4u, p.width - (x0 + x));
          uint32_t px[4];
@@ -223,13 +248,13 @@ __global__ void __launch_bounds__(512) backend_kernel(const BackendParams p) {
 
 hipError_t launch_backend(const BackendParams &p, const LaunchDims &d, hipStream_t s) {
    dim3 grid(d.tiles_per_row, d.mcu_rows, d.frames), block(d.threads);
-   void (*k)(const BackendParams) = d.direct ? backend_kernel<0, 0, true> : backend_kernel<0, 0, false>;
+   void (*k)(const BackendParams) = backend_kernel<0, 0>;
    if (p.nbcomp == 3 && p.hf[0] == 1 && p.vf[0] == 1 && p.hf[1] == p.hf[2] && p.vf[1] == p.vf[2]) {
       uint32_t h = p.hf[1], v = p.vf[1];
-      if (h == 1 && v == 1) k = d.direct ? backend_kernel<1, 1, true> : backend_kernel<1, 1, false>;
-      else if (h == 2 && v == 1) k = d.direct ? backend_kernel<2, 1, true> : backend_kernel<2, 1, false>;
-      else if (h == 2 && v == 2) k = d.direct ? backend_kernel<2, 2, true> : backend_kernel<2, 2, false>;
-      else if (h == 1 && v == 2) k = d.direct ? backend_kernel<1, 2, true> : backend_kernel<1, 2, false>;
+      if (h == 1 && v == 1) k = backend_kernel<1, 1>;
+      else if (h == 2 && v == 1) k = backend_kernel<2, 1>;
+      else if (h == 2 && v == 2) k = backend_kernel<2, 2>;
+      else if (h == 1 && v == 2) k = backend_kernel<1, 2>;
    }
    if (d.lds_bytes > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d.lds_bytes);
