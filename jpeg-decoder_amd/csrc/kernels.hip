@@ -20,6 +20,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef JM_WAVES_PER_EU
+#define JM_WAVES_PER_EU 6
+#endif
+
 namespace jpeggpu_k {
 
 using namespace jpegmath;
@@ -67,7 +71,7 @@ __device__ __forceinline__ void store_rgb_quad(uint8_t *dst, uint32_t w0, uint32
 }
 
 template <int HFC, int VFC>   // chroma factors; 0 = generic path (any factors, any component)
-__global__ void __launch_bounds__(256) backend_kernel(const BackendParams p) {
+__global__ void __launch_bounds__(256, JM_WAVES_PER_EU) backend_kernel(const BackendParams p) {
    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
    // One workgroup per tile of T MCUs, one thread per 8x8 block (B = blockDim.x rounded down).
    const uint32_t tid = threadIdx.x, nt = blockDim.x;
