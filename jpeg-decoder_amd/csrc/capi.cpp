@@ -33,6 +33,7 @@ struct State {
    bool ready = false;
    int device = -1;
    hipStream_t stream = nullptr;
+   uint32_t num_cus = 256;
    // device + pinned staging for the host-pointer entry points, grown on demand
    void *d_in = nullptr;  size_t d_in_cap = 0;
    void *d_out = nullptr; size_t d_out_cap = 0;
@@ -170,6 +171,8 @@ int jpeggpu_init(int device) {
    if (device < 0 || device >= n) return fail(JPEGGPU_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, n);
    HIP_TRY(hipSetDevice(device));
    HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+   int cus = 0;
+   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) g.num_cus = (uint32_t)cus;
    g.device = device; g.ready = true;
    g_err[0] = 0;
    return 0;

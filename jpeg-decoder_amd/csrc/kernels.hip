@@ -20,6 +20,9 @@
 
 #pragma clang fp contract(off)
 
+#ifndef JM_NT_STORE
+#define JM_NT_STORE 1      // raster bytes are written once and never re-read by the kernel: +2% measured
+#endif
 #ifndef JM_WAVES_PER_EU
 #define JM_WAVES_PER_EU 6
 #endif
@@ -60,8 +63,13 @@ __device__ __forceinline__ void store_rgb_quad(uint8_t *dst, uint32_t w0, uint32
    if ((w0 ^ w1 ^ w2) != 0x12345678u) return;
 #endif
    if (n == 4 && ((uintptr_t)dst & 3) == 0) {
+#if JM_NT_STORE
+      typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+      __builtin_nontemporal_store(u32x3{w0, w1, w2}, reinterpret_cast<u32x3 __attribute__((aligned(4))) *>(dst));
+#else
       rgb4_t v = { w0, w1, w2 };
       *reinterpret_cast<rgb4_t *>(dst) = v;
+#endif
    } else {
       uint32_t w[3] = { w0, w1, w2 };
 #pragma unroll
@@ -70,74 +78,10 @@ __device__ __forceinline__ void store_rgb_quad(uint8_t *dst, uint32_t w0, uint32
    }
 }
 
-template <int HFC, int VFC>   // chroma factors; 0 = generic path (any factors, any component)
-__global__ void __launch_bounds__(256, JM_WAVES_PER_EU) backend_kernel(const BackendParams p) {
-   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-   // One workgroup per tile of T MCUs, one thread per 8x8 block (B = blockDim.x rounded down).
-   const uint32_t tid = threadIdx.x, nt = blockDim.x;
-   const uint32_t tile = blockIdx.x, m = blockIdx.y, frame = blockIdx.z;
-   uint32_t *qt_lds = reinterpret_cast<uint32_t *>(lds + (size_t)nt * 64);
-
-   // ---- phase 1: one block per thread ----------------------------------------------------------
-   // each lane pulls its own 128-byte blocl16_t record straight into registers: 8 x 16 B, one full
-   // cache line per lane (measured 1.3x faster than staging the tile through LDS with coalesced
-   // loads, and it leaves the LDS to the u8 planes alone, so twice as many tiles are resident)
-   const bool active = tid < p.B;
-   const BlockCtx k = decode_block(p, active ? tid : 0);
-   uint4 v[8];
-   {
-      const uint32_t col = tile * k.bw + k.bxl;
-      const uint4 *src = reinterpret_cast<const uint4 *>(k.coef + (size_t)frame * k.frame_stride +
-                                                         (((size_t)m * k.vs + k.by) * k.nbH + col) * 128);
-#if defined(JM_DIAG_NOLOAD)
-      if (false) {
-#else
-      if (active && col < k.nbH) {
-#endif
-#pragma unroll
-         for (int i = 0; i < 8; i++) v[i] = src[i];
-      } else {
-#pragma unroll
-         for (int i = 0; i < 8; i++) v[i] = make_uint4(0, 0, 0, 0);
-      }
-   }
-   if (p.apply_iquant && tid < 128) qt_lds[tid] = p.qt[tid >> 5][tid & 31];
-   if (p.apply_iquant && nt < 128) qt_lds[tid + 64] = p.qt[(tid >> 5) + 2][tid & 31];   // nt == 64
-   __syncthreads();
-   if (active) {
-      uint2 rows[8];
-      {
-         f32x2 mtx[4][8];
-         const uint4 *q4 = reinterpret_cast<const uint4 *>(qt_lds + k.idq * 32);
-         uint32_t zw[32], qw[32];
-#pragma unroll
-         for (int i = 0; i < 8; i++) {
-            uint4 q = make_uint4(0x00010001u, 0x00010001u, 0x00010001u, 0x00010001u);
-            if (p.apply_iquant) q = q4[i];
-            zw[4 * i] = v[i].x; zw[4 * i + 1] = v[i].y; zw[4 * i + 2] = v[i].z; zw[4 * i + 3] = v[i].w;
-            qw[4 * i] = q.x; qw[4 * i + 1] = q.y; qw[4 * i + 2] = q.z; qw[4 * i + 3] = q.w;
-         }
-         dequant_izz_pk(zw, qw, mtx);
-#if defined(JM_DIAG_NOIDCT)
-#pragma unroll
-         for (int r = 0; r < 8; r++) { float u[8];
-#pragma unroll
-            for (int c2 = 0; c2 < 8; c2++) u[c2] = (c2 & 1) ? mtx[c2 >> 1][r].y : mtx[c2 >> 1][r].x;
-            rows[r] = pack_row(u); }
-#else
-         idct_block_hy(mtx, rows);
-#endif
-      }
-      const uint32_t pitch = k.bw * 8;
-      uint8_t *plane = lds + k.plane_off + (k.by * 8) * pitch + k.bxl * 8;
-#pragma unroll
-      for (int r = 0; r < 8; r++) *reinterpret_cast<uint2 *>(plane + r * pitch) = rows[r];
-   }
-   __syncthreads();
-
-#if defined(JM_DIAG_NOPHASE2)
-   if (p.width != 12345) return;
-#endif
+// Phase 2 of one tile: upsample + colour convert + store, from the u8 planes in LDS.
+template <int HFC, int VFC>
+__device__ __forceinline__ void pixel_phase(const BackendParams &p, const uint8_t *lds, uint32_t tid, uint32_t nt, uint32_t tile,
+                                            uint32_t m, uint32_t frame) {
    // ---- phase 2: upsample + colour convert + store ------------------------------------------
    const uint32_t x0 = tile * p.tile_w;
    if (x0 >= p.width) return;
@@ -250,16 +194,99 @@ __global__ void __launch_bounds__(256, JM_WAVES_PER_EU) backend_kernel(const Bac
    }
 }
 
+// Phase 1 of one block: dequantise + both IDCT passes in registers, 8 rows of 8 samples to the
+// component's u8 plane in LDS.  v = the block's 128-byte blocl16_t record.
+__device__ __forceinline__ void transform_block(const BackendParams &p, const BlockCtx &k, const uint4 (&v)[8], const uint32_t *qt_lds,
+                                                uint8_t *lds) {
+   uint2 rows[8];
+   {
+      f32x2 mtx[4][8];
+      const uint4 *q4 = reinterpret_cast<const uint4 *>(qt_lds + k.idq * 32);
+      uint32_t zw[32], qw[32];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+         uint4 q = make_uint4(0x00010001u, 0x00010001u, 0x00010001u, 0x00010001u);
+         if (p.apply_iquant) q = q4[i];
+         zw[4 * i] = v[i].x; zw[4 * i + 1] = v[i].y; zw[4 * i + 2] = v[i].z; zw[4 * i + 3] = v[i].w;
+         qw[4 * i] = q.x; qw[4 * i + 1] = q.y; qw[4 * i + 2] = q.z; qw[4 * i + 3] = q.w;
+      }
+      dequant_izz_pk(zw, qw, mtx);
+#if defined(JM_DIAG_NOIDCT)
+#pragma unroll
+      for (int r = 0; r < 8; r++) { float u[8];
+#pragma unroll
+         for (int c2 = 0; c2 < 8; c2++) u[c2] = (c2 & 1) ? mtx[c2 >> 1][r].y : mtx[c2 >> 1][r].x;
+         rows[r] = pack_row(u); }
+#else
+      idct_block_hy(mtx, rows);
+#endif
+   }
+   const uint32_t pitch = k.bw * 8;
+   uint8_t *plane = lds + k.plane_off + (k.by * 8) * pitch + k.bxl * 8;
+#pragma unroll
+   for (int r = 0; r < 8; r++) *reinterpret_cast<uint2 *>(plane + r * pitch) = rows[r];
+}
+
+__device__ __forceinline__ const uint8_t *record_ptr(const BlockCtx &k, uint32_t tile, uint32_t m, uint32_t frame, bool &in_plane) {
+   const uint32_t col = tile * k.bw + k.bxl;
+   in_plane = col < k.nbH;
+   return k.coef + (size_t)frame * k.frame_stride + (((size_t)m * k.vs + k.by) * k.nbH + col) * 128;
+}
+
+// ---- the fused back end: one workgroup per tile, records loaded straight into registers ----------
+// One workgroup = one tile of T MCUs of one MCU row, one thread per 8x8 block.  Each lane pulls its
+// own 128-byte record with 8 x 16-byte loads (one full cache line per lane; tools/ubench_read.hip:
+// 6.4-6.7 TB/s, no slower than lane-coalesced loads and no LDS staging or extra barrier needed).
+template <int HFC, int VFC>   // chroma factors; 0 = generic path (any factors, any component)
+__global__ void __launch_bounds__(256, JM_WAVES_PER_EU) backend_kernel(const BackendParams p) {
+   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+   const uint32_t tid = threadIdx.x, nt = blockDim.x;
+   const uint32_t tile = blockIdx.x, m = blockIdx.y, frame = blockIdx.z;
+   uint32_t *qt_lds = reinterpret_cast<uint32_t *>(lds + (size_t)nt * 64);
+   const bool active = tid < p.B;
+   const BlockCtx k = decode_block(p, active ? tid : 0);
+   uint4 v[8];
+   {
+      bool in_plane;
+      const uint4 *src = reinterpret_cast<const uint4 *>(record_ptr(k, tile, m, frame, in_plane));
+#if defined(JM_DIAG_NOLOAD)
+      in_plane = false;
+#endif
+      if (active && in_plane) {
+#pragma unroll
+         for (int i = 0; i < 8; i++) v[i] = src[i];   // NOT non-temporal: a lane's 8 loads share one line (nt: 1.6x slower)
+      } else {
+#pragma unroll
+         for (int i = 0; i < 8; i++) v[i] = make_uint4(0, 0, 0, 0);
+      }
+   }
+   if (p.apply_iquant && tid < 128) qt_lds[tid] = p.qt[tid >> 5][tid & 31];
+   if (p.apply_iquant && nt < 128) qt_lds[tid + 64] = p.qt[(tid >> 5) + 2][tid & 31];   // nt == 64
+   __syncthreads();
+   if (active) transform_block(p, k, v, qt_lds, lds);
+   __syncthreads();
+#if !defined(JM_DIAG_NOPHASE2)
+   pixel_phase<HFC, VFC>(p, lds, tid, nt, tile, m, frame);
+#endif
+}
+
+typedef void (*BackendFn)(const BackendParams);
+static BackendFn pick_kernel(const BackendParams &p) {
+#define JM_PICK(H, V) ((BackendFn)backend_kernel<H, V>)
+   if (p.nbcomp == 3 && p.hf[0] == 1 && p.vf[0] == 1 && p.hf[1] == p.hf[2] && p.vf[1] == p.vf[2]) {
+      const uint32_t h = p.hf[1], v = p.vf[1];
+      if (h == 1 && v == 1) return JM_PICK(1, 1);
+      if (h == 2 && v == 1) return JM_PICK(2, 1);
+      if (h == 2 && v == 2) return JM_PICK(2, 2);
+      if (h == 1 && v == 2) return JM_PICK(1, 2);
+   }
+   return JM_PICK(0, 0);
+#undef JM_PICK
+}
+
 hipError_t launch_backend(const BackendParams &p, const LaunchDims &d, hipStream_t s) {
    dim3 grid(d.tiles_per_row, d.mcu_rows, d.frames), block(d.threads);
-   void (*k)(const BackendParams) = backend_kernel<0, 0>;
-   if (p.nbcomp == 3 && p.hf[0] == 1 && p.vf[0] == 1 && p.hf[1] == p.hf[2] && p.vf[1] == p.vf[2]) {
-      uint32_t h = p.hf[1], v = p.vf[1];
-      if (h == 1 && v == 1) k = backend_kernel<1, 1>;
-      else if (h == 2 && v == 1) k = backend_kernel<2, 1>;
-      else if (h == 2 && v == 2) k = backend_kernel<2, 2>;
-      else if (h == 1 && v == 2) k = backend_kernel<1, 2>;
-   }
+   BackendFn k = pick_kernel(p);
    if (d.lds_bytes > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d.lds_bytes);
       if (e != hipSuccess) return e;
