@@ -1,0 +1,106 @@
+/*
+ * jpeggpu_decode.h -- host front end + output stage around the GPU pixel back end (SURVEY §8f rows
+ * f1-f3): JPEG header parser, Huffman VLD into full-frame blocl16_t planes, per-scan hand-off of
+ * progressive files, PPM/PGM writer.  The entropy decoder is serial host code (as in the
+ * reference); every pixel is still produced by jpeggpu_backend_run* on the GPU.
+ *
+ * Citations are file:line under the reference tree.  Behaviour is the REFERENCE's, not the
+ * standard's, wherever the two differ (listed in DESIGN.md §8): e.g. refinement bits are OR-ed
+ * into the coefficient whatever its sign (src/vld.c:177-183), DC scans always walk whole MCUs
+ * (src/progressive.c:98-124), only APP0/COM/DQT/DHT/SOF0/SOF2/SOS/EOI markers are accepted
+ * (src/entete.c:288-327).
+ */
+#ifndef JPEGGPU_DECODE_H
+#define JPEGGPU_DECODE_H
+
+#include "jpeggpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Positive status codes are erreur_code_t values (include/erreur.h:9-79), so a CLI built on this
+ * library exits with the same code as the reference's main (src/jpeg2ppm.c:70-72,93-96,129-133). */
+enum {
+   JPEGGPU_ERR_0XFF00 = 1, JPEGGPU_ERR_AC_BAD, JPEGGPU_ERR_DC_BAD, JPEGGPU_ERR_SOF_BAD, JPEGGPU_ERR_HUFF_CODE_1,
+   JPEGGPU_ERR_DIFF_AH_AL, JPEGGPU_ERR_PARAM, JPEGGPU_ERR_OPT, JPEGGPU_ERR_NO_HT, JPEGGPU_ERR_NO_QT_REF,
+   JPEGGPU_ERR_INVALID_FILE_PATH, JPEGGPU_ERR_INVALID_FILE_EXT, /* 13 = JPEGGPU_ERR_NB_COMP */
+   JPEGGPU_ERR_SOF_NON_SUPPORTE = 14, JPEGGPU_ERR_APP0_LEN, JPEGGPU_ERR_NO_APP0, JPEGGPU_ERR_COMP_ID, JPEGGPU_ERR_COM_LEN,
+   JPEGGPU_ERR_DHT_START_0, JPEGGPU_ERR_DHT_LEN, JPEGGPU_ERR_NO_DHT, JPEGGPU_ERR_DQT_LEN, JPEGGPU_ERR_DQT_PRECISION,
+   JPEGGPU_ERR_DQT_ID, JPEGGPU_ERR_NO_DQT, JPEGGPU_ERR_EOI_BEFORE_SOS, JPEGGPU_ERR_NO_EOI, JPEGGPU_ERR_HUFF_BAD,
+   JPEGGPU_ERR_HUFF_ID, JPEGGPU_ERR_HUFF_MORE_256, JPEGGPU_ERR_JFIF_VERSION, JPEGGPU_ERR_NO_JFIF, JPEGGPU_ERR_MARKER_BAD,
+   JPEGGPU_ERR_MARKER_UNKNOWN, JPEGGPU_ERR_SEVERAL_SOF, JPEGGPU_ERR_SOF_PRECISION, JPEGGPU_ERR_SOF_LEN, JPEGGPU_ERR_NO_SOF,
+   JPEGGPU_ERR_SEVERAL_SOI, JPEGGPU_ERR_NO_SOI, JPEGGPU_ERR_SOS_COMP_ID, JPEGGPU_ERR_SOS_SS, JPEGGPU_ERR_SOS_SE,
+   JPEGGPU_ERR_SOS_AH, JPEGGPU_ERR_SOS_AL, JPEGGPU_ERR_SOS_NB_COMP, JPEGGPU_ERR_SOS_LEN,
+   /* library-specific */
+   JPEGGPU_ERR_UNSUPPORTED = -6,   /* input for which the reference itself has no defined behaviour (it reads
+                                      uninitialised or NULL data): a baseline scan that lacks a component,
+                                      a first scan whose component order is not Y,Cb,Cr with unequal
+                                      sampling, coefficient runs that leave the block                     */
+   JPEGGPU_ERR_IO = -7
+};
+
+typedef struct jpeggpu_jpeg jpeggpu_jpeg_t;
+
+/* What decode_entete left in img_t after the current SOS (include/img.h:88-103, :66-75).        */
+typedef struct jpeggpu_scan_info_s {
+   uint8_t num_sof;          /* 0 baseline, 2 progressive (section_done_t.num_sof)                */
+   uint8_t nb_scan_comp;     /* components named by the SOS                                       */
+   uint8_t scan_comp[3];     /* their FRAME indices (get_composante, src/decoder_utils.c:36-46)   */
+   uint8_t ss, se, ah, al;   /* other_t                                                           */
+   uint8_t eoi;              /* EOI reached: no scan pending                                      */
+   uint16_t scans_decoded;   /* scans entropy-decoded so far                                      */
+   uint32_t mcu_rows_done;   /* baseline: complete MCU rows of the scan, = nbmcuV unless it failed
+                                (the reference has written exactly those rows, src/baseline.c:201-217) */
+} jpeggpu_scan_info_t;
+
+/* decode_entete(fichier, true, img) (src/entete.c:199-248): checks SOI/EOI, parses markers up to
+ * and including the first SOS, derives the geometry, runs the baseline/progressive header
+ * verifications and allocates zeroed full-frame planes (init_sortie, src/progressive.c:73-84, but
+ * contiguous).  <data> is borrowed and must outlive the handle.                                  */
+int  jpeggpu_jpeg_open_memory(const uint8_t *data, size_t len, jpeggpu_jpeg_t **out);
+/* Same, after ouverture_fichier_in's checks (src/utils.c:43-54: extension .jpeg/.jpg, readable). */
+int  jpeggpu_jpeg_open_file(const char *path, jpeggpu_jpeg_t **out);
+void jpeggpu_jpeg_close(jpeggpu_jpeg_t *j);
+
+int  jpeggpu_jpeg_frame_desc(const jpeggpu_jpeg_t *j, jpeggpu_frame_desc_t *desc);   /* apply_iquant = 1 */
+int  jpeggpu_jpeg_scan_info(const jpeggpu_jpeg_t *j, jpeggpu_scan_info_t *info);
+/* Quantisation table <idq> as currently defined (NULL if absent); zigzag order like qtable_t.    */
+const jpeggpu_qtable_t  *jpeggpu_jpeg_qtable(const jpeggpu_jpeg_t *j, int idq);
+/* Host plane of frame component c: QUANTISED zigzag blocks, (blocY*nbH_c + blocX).               */
+const jpeggpu_blocl16_t *jpeggpu_jpeg_plane(const jpeggpu_jpeg_t *j, int c);
+int  jpeggpu_jpeg_nb_comments(const jpeggpu_jpeg_t *j);
+const char *jpeggpu_jpeg_comment(const jpeggpu_jpeg_t *j, int i);
+
+/* Entropy-decodes the pending scan into the planes and finishes its last byte:
+ * baseline   = the MCU walk of decode_baseline_image (src/baseline.c:160-199) without the pixel
+ *              stages (coefficients stay quantised; the GPU applies iquant, same int16 arithmetic),
+ * progressive = decode_progressif_dc / decode_progressif_ac + finir_octet (src/progressive.c:98-173,
+ *              :220-232).  Host only, no GPU needed.                                              */
+int  jpeggpu_jpeg_decode_scan(jpeggpu_jpeg_t *j);
+/* decode_entete(fichier, false, img) (src/progressive.c:322): markers up to the next SOS or EOI.  */
+int  jpeggpu_jpeg_next_header(jpeggpu_jpeg_t *j);
+
+/* The pixel back end over the current planes (GPU): host raster out, layout of
+ * jpeggpu_backend_run.  Planes stay resident on the device between calls; only components
+ * touched by scans since the previous render are uploaded again.                                 */
+int  jpeggpu_jpeg_render(jpeggpu_jpeg_t *j, uint8_t *out, size_t out_stride);
+
+/* Output stage: "P5\n"|"P6\n", "%d %d\n", "255\n" (src/baseline.c:121-130, src/progressive.c:241-244)
+ * followed by ALL raster rows, padded ones included (src/decoder_utils.c:51,68).                 */
+int  jpeggpu_write_pnm(const char *path, const jpeggpu_frame_desc_t *desc, const uint8_t *raster, size_t stride);
+
+/* out_file_name (src/utils.c:56-90): <outfile or input path> with "-<nb>" inserted before the
+ * extension when nb != 0; without outfile the extension becomes .pgm/.ppm.  Returns the length
+ * written (excluding NUL) or a negative status.                                                   */
+int  jpeggpu_out_file_name(const char *filepath, const char *outfile, uint8_t nbcomp, uint8_t nb, char *buf, size_t cap);
+
+/* The whole of main() for one file (src/jpeg2ppm.c:62-141): baseline -> one image; progressive ->
+ * one image per scan, "<name>-<k>.<ext>", and a symbolic link "<name>.<ext>" to the last one
+ * (src/progressive.c:332-343).  *nb_images receives the number of images written.                */
+int  jpeggpu_jpeg2ppm(const char *filepath, const char *outfile, int *nb_images);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JPEGGPU_DECODE_H */

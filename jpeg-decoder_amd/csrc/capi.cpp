@@ -162,6 +162,10 @@ extern "C" {
 
 const char *jpeggpu_last_error(void) { return g_err; }
 
+// used by decode_api.cpp (same library); not part of the public headers
+void jpeggpu_internal_set_error(const char *msg) { snprintf(g_err, sizeof g_err, "%s", msg ? msg : ""); }
+int jpeggpu_internal_ensure_init(void) { return ensure_init(); }
+
 int jpeggpu_init(int device) {
    std::lock_guard<std::mutex> lk(g_mu);
    if (g.ready && g.device == device) return 0;

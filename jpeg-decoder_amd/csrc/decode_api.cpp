@@ -1,0 +1,415 @@
+// decode_api.cpp -- C ABI of include/jpeggpu_decode.h: the host front end (frontend.cpp) wired to
+// the GPU back end, the per-scan hand-off of progressive files and the PPM/PGM output stage.
+//
+// Coefficient planes live in pinned host memory when a GPU is present (the entropy decoder writes
+// straight into the buffer hipMemcpyAsync reads), stay resident on the device between scans, and
+// only the components a scan touched are uploaded again.  Upload, kernel and download of scan k
+// are queued on one stream; the host goes on to parse and decode scan k+1 as soon as the upload
+// has been read (event), so the GPU work of a scan overlaps the entropy decoding of the next.
+#include <hip/hip_runtime_api.h>
+
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "../../include/jpeggpu_decode.h"
+#include "frontend.hpp"
+
+namespace {
+
+thread_local char g_derr[512] = "";
+
+int dfail(int code, const char *fmt, ...) {
+   va_list ap;
+   va_start(ap, fmt);
+   vsnprintf(g_derr, sizeof g_derr, fmt, ap);
+   va_end(ap);
+   return code;
+}
+
+}  // namespace
+
+// capi.cpp: lets this file report through jpeggpu_last_error()
+extern "C" void jpeggpu_internal_set_error(const char *msg);
+extern "C" int jpeggpu_internal_ensure_init(void);
+
+struct jpeggpu_jpeg {
+   jpegfe::Decoder d;
+   bool pinned = false;
+   size_t plane_bytes[3] = { 0, 0, 0 };
+   // device side, created by the first render
+   bool gpu = false;
+   hipStream_t stream = nullptr;
+   hipEvent_t uploaded = nullptr;
+   void *d_plane[3] = { nullptr, nullptr, nullptr };
+   void *d_out = nullptr;
+   uint8_t *h_out = nullptr;      // pinned raster
+   size_t out_bytes = 0;
+   bool in_flight = false;        // a render has been queued and not yet waited for
+};
+
+namespace {
+
+int report(jpeggpu_jpeg *j, int rc) {
+   if (rc) jpeggpu_internal_set_error(j->d.err.c_str());
+   return rc;
+}
+
+#define HIP_TRYD(expr)                                                                       \
+   do {                                                                                      \
+      hipError_t e_ = (expr);                                                                \
+      if (e_ != hipSuccess) {                                                                \
+         dfail(JPEGGPU_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));                      \
+         jpeggpu_internal_set_error(g_derr);                                                 \
+         return JPEGGPU_ERR_HIP;                                                             \
+      }                                                                                      \
+   } while (0)
+
+bool have_device() {
+   int n = 0;
+   return hipGetDeviceCount(&n) == hipSuccess && n > 0;
+}
+
+int alloc_planes(jpeggpu_jpeg *j) {
+   jpegfe::Decoder &d = j->d;
+   j->pinned = have_device() && jpeggpu_internal_ensure_init() == 0;
+   for (int c = 0; c < d.nbcomp; c++) {
+      size_t bytes = d.plane_blocks(c) * sizeof(jpeggpu_blocl16_t);
+      j->plane_bytes[c] = bytes;
+      void *p = nullptr;
+      if (bytes == 0) bytes = 128;
+      if (j->pinned) {
+         if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) p = nullptr;
+      } else {
+         p = malloc(bytes);
+      }
+      if (!p) return dfail(JPEGGPU_ERR_IO, "allocation de %zu octets impossible", bytes);
+      memset(p, 0, bytes);
+      d.plane[c] = (int16_t *)p;
+   }
+   return 0;
+}
+
+void free_all(jpeggpu_jpeg *j) {
+   if (j->gpu) {
+      if (j->stream) (void)hipStreamSynchronize(j->stream);
+      for (int c = 0; c < 3; c++) if (j->d_plane[c]) (void)hipFree(j->d_plane[c]);
+      if (j->d_out) (void)hipFree(j->d_out);
+      if (j->h_out) (void)hipHostFree(j->h_out);
+      if (j->uploaded) (void)hipEventDestroy(j->uploaded);
+      if (j->stream) (void)hipStreamDestroy(j->stream);
+   }
+   for (int c = 0; c < 3; c++)
+      if (j->d.plane[c]) { if (j->pinned) (void)hipHostFree(j->d.plane[c]); else free(j->d.plane[c]); }
+   delete j;
+}
+
+int open_common(jpeggpu_jpeg *j, jpeggpu_jpeg_t **out) {
+   int rc = j->d.open();
+   if (rc) { report(j, rc); free_all(j); return rc; }
+   rc = alloc_planes(j);
+   if (rc) { jpeggpu_internal_set_error(g_derr); free_all(j); return rc; }
+   *out = j;
+   return 0;
+}
+
+void fill_desc(const jpegfe::Decoder &d, jpeggpu_frame_desc_t *desc) {
+   memset(desc, 0, sizeof *desc);
+   desc->width = d.width; desc->height = d.height; desc->nbcomp = d.nbcomp;
+   desc->max_h = d.max_h; desc->max_v = d.max_v; desc->apply_iquant = 1;
+   desc->nbmcuH = d.nbmcuH; desc->nbmcuV = d.nbmcuV;
+   for (int c = 0; c < d.nbcomp && c < 3; c++) {
+      desc->comp[c].hs = d.comp[c].hs; desc->comp[c].vs = d.comp[c].vs; desc->comp[c].idq = d.comp[c].idq;
+   }
+}
+
+// Queue upload of the dirty planes, the fused kernel and the download of the raster.
+int render_begin(jpeggpu_jpeg *j) {
+   jpegfe::Decoder &d = j->d;
+   jpeggpu_frame_desc_t desc;
+   fill_desc(d, &desc);
+   const jpeggpu_qtable_t *qt[4];
+   for (int i = 0; i < 4; i++) qt[i] = d.qt_present[i] ? (const jpeggpu_qtable_t *)d.qt[i] : nullptr;
+   // src/progressive.c:262-267: a component without its table is ERR_NO_HT there
+   for (int c = 0; c < d.nbcomp; c++)
+      if (d.comp[c].idq > 3 || !qt[d.comp[c].idq]) {
+         dfail(JPEGGPU_ERR_NO_HT, "Pas de table de quantification pour la composante %d", c);
+         jpeggpu_internal_set_error(g_derr);
+         return JPEGGPU_ERR_NO_HT;
+      }
+   int rc = jpeggpu_internal_ensure_init();
+   if (rc) return rc;
+   if (!j->gpu) {
+      HIP_TRYD(hipStreamCreateWithFlags(&j->stream, hipStreamNonBlocking));
+      HIP_TRYD(hipEventCreateWithFlags(&j->uploaded, hipEventDisableTiming));
+      for (int c = 0; c < d.nbcomp; c++) {
+         HIP_TRYD(hipMalloc(&j->d_plane[c], j->plane_bytes[c] ? j->plane_bytes[c] : 128));
+         d.dirty[c] = true;
+      }
+      j->out_bytes = jpeggpu_raster_rows(&desc) * jpeggpu_raster_row_bytes(&desc);
+      HIP_TRYD(hipMalloc(&j->d_out, j->out_bytes ? j->out_bytes : 16));
+      HIP_TRYD(hipHostMalloc((void **)&j->h_out, j->out_bytes ? j->out_bytes : 16, hipHostMallocDefault));
+      j->gpu = true;
+   }
+   for (int c = 0; c < d.nbcomp; c++)
+      if (d.dirty[c] && j->plane_bytes[c]) {
+         HIP_TRYD(hipMemcpyAsync(j->d_plane[c], d.plane[c], j->plane_bytes[c], hipMemcpyHostToDevice, j->stream));
+         d.dirty[c] = false;
+      }
+   HIP_TRYD(hipEventRecord(j->uploaded, j->stream));
+   rc = jpeggpu_backend_run_device(&desc, (const void *const *)j->d_plane, qt, j->d_out, 0, j->stream);
+   if (rc) return rc;
+   HIP_TRYD(hipMemcpyAsync(j->h_out, j->d_out, j->out_bytes, hipMemcpyDeviceToHost, j->stream));
+   j->in_flight = true;
+   return 0;
+}
+
+// The planes may be written again (next scan) once the upload has been consumed.
+int render_planes_free(jpeggpu_jpeg *j) {
+   if (j->in_flight) HIP_TRYD(hipEventSynchronize(j->uploaded));
+   return 0;
+}
+
+int render_end(jpeggpu_jpeg *j) {
+   if (j->in_flight) HIP_TRYD(hipStreamSynchronize(j->stream));
+   j->in_flight = false;
+   return 0;
+}
+
+int write_pnm(const char *path, const jpeggpu_frame_desc_t *desc, const uint8_t *raster, size_t stride, size_t rows) {
+   FILE *f = fopen(path, "w");
+   if (!f) return dfail(JPEGGPU_ERR_IO, "ouverture de '%s' impossible", path);
+   const size_t rb = jpeggpu_raster_row_bytes(desc);
+   fprintf(f, desc->nbcomp == 1 ? "P5\n" : "P6\n");
+   fprintf(f, "%d %d\n", desc->width, desc->height);
+   fprintf(f, "255\n");
+   bool ok = true;
+   if (rows && rb) {
+      if (stride == rb) ok = fwrite(raster, 1, rb * rows, f) == rb * rows;
+      else for (size_t r = 0; r < rows && ok; r++) ok = fwrite(raster + r * stride, 1, rb, f) == rb;
+   }
+   if (fclose(f) != 0) ok = false;
+   return ok ? 0 : dfail(JPEGGPU_ERR_IO, "écriture de '%s' incomplète", path);
+}
+
+std::string out_name(const char *filepath, const char *outfile, uint8_t nbcomp, uint8_t nb) {
+   std::string base = outfile ? outfile : filepath;
+   size_t dot = base.rfind('.');
+   std::string ext = dot == std::string::npos ? std::string() : base.substr(dot);
+   std::string name = dot == std::string::npos ? base : base.substr(0, dot);
+   if (nb != 0) name += "-" + std::to_string((unsigned)nb);
+   if (!outfile) name += nbcomp == 1 ? ".pgm" : (nbcomp == 3 ? ".ppm" : "");
+   else name += ext;
+   return name;
+}
+
+}  // namespace
+
+extern "C" {
+
+int jpeggpu_jpeg_open_memory(const uint8_t *data, size_t len, jpeggpu_jpeg_t **out) {
+   if (!data || !out) { jpeggpu_internal_set_error("NULL argument"); return JPEGGPU_ERR_INVALID_ARG; }
+   *out = nullptr;
+   jpeggpu_jpeg *j = new jpeggpu_jpeg();
+   j->d.data = data;
+   j->d.len = len;
+   return open_common(j, out);
+}
+
+int jpeggpu_jpeg_open_file(const char *path, jpeggpu_jpeg_t **out) {
+   if (!path || !out) { jpeggpu_internal_set_error("NULL argument"); return JPEGGPU_ERR_INVALID_ARG; }
+   *out = nullptr;
+   // ouverture_fichier_in, src/utils.c:43-54
+   const char *dot = strrchr(path, '.');
+   if (!dot || !(strcmp(dot + 1, "jpeg") == 0 || strcmp(dot + 1, "jpg") == 0)) {
+      jpeggpu_internal_set_error("Mauvaise extension de fichier.");
+      return JPEGGPU_ERR_INVALID_FILE_EXT;
+   }
+   FILE *f = fopen(path, "r");
+   if (!f) { jpeggpu_internal_set_error("Fichier introuvable."); return JPEGGPU_ERR_INVALID_FILE_PATH; }
+   jpeggpu_jpeg *j = new jpeggpu_jpeg();
+   fseek(f, 0, SEEK_END);
+   long sz = ftell(f);
+   fseek(f, 0, SEEK_SET);
+   j->d.owned.resize(sz > 0 ? (size_t)sz : 0);
+   size_t got = sz > 0 ? fread(j->d.owned.data(), 1, (size_t)sz, f) : 0;
+   fclose(f);
+   j->d.owned.resize(got);
+   j->d.data = j->d.owned.data();
+   j->d.len = got;
+   return open_common(j, out);
+}
+
+void jpeggpu_jpeg_close(jpeggpu_jpeg_t *j) { if (j) free_all(j); }
+
+int jpeggpu_jpeg_frame_desc(const jpeggpu_jpeg_t *j, jpeggpu_frame_desc_t *desc) {
+   if (!j || !desc) return JPEGGPU_ERR_INVALID_ARG;
+   fill_desc(j->d, desc);
+   return 0;
+}
+
+int jpeggpu_jpeg_scan_info(const jpeggpu_jpeg_t *j, jpeggpu_scan_info_t *info) {
+   if (!j || !info) return JPEGGPU_ERR_INVALID_ARG;
+   memset(info, 0, sizeof *info);
+   const jpegfe::Decoder &d = j->d;
+   info->num_sof = d.num_sof;
+   for (unsigned k = 0; k < 3; k++) {
+      int c = d.get_composante(k);
+      if (c < 0) break;
+      info->scan_comp[info->nb_scan_comp++] = (uint8_t)c;
+   }
+   info->ss = d.ss; info->se = d.se; info->ah = d.ah; info->al = d.al;
+   info->eoi = d.eoi_done;
+   info->scans_decoded = (uint16_t)d.scans_decoded;
+   info->mcu_rows_done = d.mcu_rows_done;
+   return 0;
+}
+
+const jpeggpu_qtable_t *jpeggpu_jpeg_qtable(const jpeggpu_jpeg_t *j, int idq) {
+   if (!j || idq < 0 || idq > 3 || !j->d.qt_present[idq]) return nullptr;
+   return (const jpeggpu_qtable_t *)j->d.qt[idq];
+}
+
+const jpeggpu_blocl16_t *jpeggpu_jpeg_plane(const jpeggpu_jpeg_t *j, int c) {
+   if (!j || c < 0 || c >= j->d.nbcomp || c > 2) return nullptr;
+   return (const jpeggpu_blocl16_t *)j->d.plane[c];
+}
+
+int jpeggpu_jpeg_nb_comments(const jpeggpu_jpeg_t *j) { return j ? (int)j->d.comments.size() : 0; }
+const char *jpeggpu_jpeg_comment(const jpeggpu_jpeg_t *j, int i) {
+   return (j && i >= 0 && i < (int)j->d.comments.size()) ? j->d.comments[i].c_str() : nullptr;
+}
+
+int jpeggpu_jpeg_decode_scan(jpeggpu_jpeg_t *j) {
+   if (!j) return JPEGGPU_ERR_INVALID_ARG;
+   int rc = render_planes_free(j);
+   if (rc) return rc;
+   return report(j, j->d.decode_scan());
+}
+
+int jpeggpu_jpeg_next_header(jpeggpu_jpeg_t *j) {
+   if (!j) return JPEGGPU_ERR_INVALID_ARG;
+   return report(j, j->d.next_header());
+}
+
+int jpeggpu_jpeg_render(jpeggpu_jpeg_t *j, uint8_t *out, size_t out_stride) {
+   if (!j || !out) { jpeggpu_internal_set_error("NULL argument"); return JPEGGPU_ERR_INVALID_ARG; }
+   jpeggpu_frame_desc_t desc;
+   fill_desc(j->d, &desc);
+   const size_t rb = jpeggpu_raster_row_bytes(&desc), rows = jpeggpu_raster_rows(&desc);
+   if (out_stride == 0) out_stride = rb;
+   if (out_stride < rb) { jpeggpu_internal_set_error("out_stride plus petit qu'une ligne"); return JPEGGPU_ERR_INVALID_ARG; }
+   int rc = render_begin(j);
+   if (rc) return rc;
+   rc = render_end(j);
+   if (rc) return rc;
+   if (out_stride == rb) memcpy(out, j->h_out, rb * rows);
+   else for (size_t r = 0; r < rows; r++) memcpy(out + r * out_stride, j->h_out + r * rb, rb);
+   return 0;
+}
+
+int jpeggpu_write_pnm(const char *path, const jpeggpu_frame_desc_t *desc, const uint8_t *raster, size_t stride) {
+   if (!path || !desc || !raster) { jpeggpu_internal_set_error("NULL argument"); return JPEGGPU_ERR_INVALID_ARG; }
+   if (desc->nbcomp != 1 && desc->nbcomp != 3) { jpeggpu_internal_set_error("Il faut une ou trois composante"); return JPEGGPU_ERR_NB_COMP; }
+   const size_t rb = jpeggpu_raster_row_bytes(desc);
+   if (stride == 0) stride = rb;
+   int rc = write_pnm(path, desc, raster, stride, jpeggpu_raster_rows(desc));
+   if (rc) jpeggpu_internal_set_error(g_derr);
+   return rc;
+}
+
+int jpeggpu_out_file_name(const char *filepath, const char *outfile, uint8_t nbcomp, uint8_t nb, char *buf, size_t cap) {
+   if (!filepath || !buf) return JPEGGPU_ERR_INVALID_ARG;
+   std::string n = out_name(filepath, outfile, nbcomp, nb);
+   if (n.size() + 1 > cap) return JPEGGPU_ERR_INVALID_ARG;
+   memcpy(buf, n.c_str(), n.size() + 1);
+   return (int)n.size();
+}
+
+int jpeggpu_jpeg2ppm(const char *filepath, const char *outfile, int *nb_images) {
+   if (nb_images) *nb_images = 0;
+   // verif_option_io, src/jpeg2ppm.c:25-60
+   if (!filepath) { jpeggpu_internal_set_error("Pas de fichier jpeg/jpg"); return JPEGGPU_ERR_INVALID_FILE_PATH; }
+   if (access(filepath, R_OK)) {
+      dfail(JPEGGPU_ERR_INVALID_FILE_PATH, "Pas de fichier '%s'", filepath);
+      jpeggpu_internal_set_error(g_derr);
+      return JPEGGPU_ERR_INVALID_FILE_PATH;
+   }
+   if (outfile) {
+      std::string o = outfile;
+      size_t sl = o.rfind('/');
+      std::string folder = sl == std::string::npos ? "." : (sl == 0 ? "/" : o.substr(0, sl));
+      struct stat sb;
+      if (stat(folder.c_str(), &sb) == -1) mkdir(folder.c_str(), S_IRWXU | S_IRGRP | S_IXGRP | S_IROTH | S_IXOTH);
+   }
+   jpeggpu_jpeg_t *j = nullptr;
+   int rc = jpeggpu_jpeg_open_file(filepath, &j);
+   if (rc) return rc;
+   jpeggpu_frame_desc_t desc;
+   fill_desc(j->d, &desc);
+   const size_t rb = jpeggpu_raster_row_bytes(&desc);
+   int written = 0;
+
+   if (j->d.num_sof == 0) {
+      // decode_baseline_image, src/baseline.c:89-231: the output file exists (header + the complete MCU
+      // rows) even when the scan turns out to be corrupt
+      std::string name = out_name(filepath, outfile, desc.nbcomp, 0);
+      int drc = report(j, j->d.decode_scan());
+      std::string derr = j->d.err;
+      size_t rows = drc ? (size_t)j->d.mcu_rows_done * desc.max_v * 8 : jpeggpu_raster_rows(&desc);
+      if (drc) for (int c = 0; c < desc.nbcomp; c++) j->d.dirty[c] = true;
+      rc = 0;
+      if (rows && rb) { rc = render_begin(j); if (!rc) rc = render_end(j); }
+      if (!rc) {
+         rc = write_pnm(name.c_str(), &desc, j->h_out, rb, rows);
+         if (rc) jpeggpu_internal_set_error(g_derr);
+         else written = 1;
+      }
+      if (drc) { jpeggpu_internal_set_error(derr.c_str()); rc = drc; }
+   } else {
+      // decode_progressive_image, src/progressive.c:188-349: one image per scan
+      uint64_t k = 1;
+      std::string pending_name;
+      auto flush = [&]() -> int {   // wait for the queued render and write its file
+         if (pending_name.empty()) return 0;
+         int r = render_end(j);
+         if (!r) { r = write_pnm(pending_name.c_str(), &desc, j->h_out, rb, jpeggpu_raster_rows(&desc)); if (r) jpeggpu_internal_set_error(g_derr); else written++; }
+         pending_name.clear();
+         return r;
+      };
+      while (!j->d.eoi_done) {
+         int drc = report(j, j->d.decode_scan());       // overlaps the kernel + download of the previous scan
+         std::string derr = j->d.err;
+         rc = flush();
+         if (drc) { jpeggpu_internal_set_error(derr.c_str()); rc = drc; }
+         if (rc) break;
+         rc = render_begin(j);
+         if (rc) break;
+         pending_name = out_name(filepath, outfile, desc.nbcomp, (uint8_t)k);   // uint8_t parameter, src/utils.c:56
+         rc = render_planes_free(j);
+         if (rc) break;
+         int hrc = report(j, j->d.next_header());
+         if (hrc) { std::string herr = j->d.err; rc = flush(); jpeggpu_internal_set_error(herr.c_str()); rc = hrc; break; }
+         k++;
+      }
+      if (!rc) rc = flush();
+      if (!rc && k > 1) {
+         // src/progressive.c:332-343: "ln -f -s <last image> <name>"
+         std::string base = out_name(filepath, outfile, desc.nbcomp, 0), last = out_name(filepath, outfile, desc.nbcomp, (uint8_t)(k - 1));
+         size_t sl = last.rfind('/');
+         std::string target = sl == std::string::npos ? last : last.substr(sl + 1);
+         unlink(base.c_str());
+         if (symlink(target.c_str(), base.c_str()) != 0) { /* the reference ignores ln's status */ }
+      }
+   }
+   if (nb_images) *nb_images = written;
+   jpeggpu_jpeg_close(j);
+   return rc;
+}
+
+}  // extern "C"

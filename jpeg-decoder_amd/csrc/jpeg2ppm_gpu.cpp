@@ -1,0 +1,46 @@
+// jpeg2ppm_gpu -- thin command-line driver over jpeggpu_jpeg2ppm: same arguments for input and
+// output file as the reference's jpeg2ppm (src/options.c:58-66: "-o <fichier>" / "--outfile=<fichier>")
+// and the same exit status (the erreur_code_t of the failure, src/jpeg2ppm.c:70-72,93-96,129-133).
+// Everything else of the reference's CLI (timers, verbose, table dumps) is out of scope.
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/jpeggpu_decode.h"
+
+static int usage(const char *exe, int code, const char *why) {
+   if (why) fprintf(stderr, "Erreur %d : %s\n", code, why);
+   fprintf(stderr, "Usage : %s [-o <fichier> | --outfile=<fichier>] fichier.jpg|fichier.jpeg\n", exe);
+   return code;
+}
+
+int main(int argc, char **argv) {
+   const char *in = nullptr, *out = nullptr;
+   for (int i = 1; i < argc; i++) {
+      const char *a = argv[i];
+      if (a[0] != '-') {
+         if (in) return usage(argv[0], JPEGGPU_ERR_PARAM, "Deux images passées en paramètre.");
+         in = a;
+      } else if (strcmp(a, "-h") == 0 || strcmp(a, "--help") == 0) {
+         usage(argv[0], 0, nullptr);
+         return 0;
+      } else if (strcmp(a, "-o") == 0) {
+         if (i + 1 >= argc) return usage(argv[0], JPEGGPU_ERR_OPT, "Manque la valeur pour le paramètre 'o'");
+         if (out) return usage(argv[0], JPEGGPU_ERR_PARAM, "Maximum une image en output.");
+         out = argv[++i];
+      } else if (strncmp(a, "--outfile=", 10) == 0) {
+         if (a[10] == 0) return usage(argv[0], JPEGGPU_ERR_PARAM, "Manque la valeur pour le paramètre 'outfile'");
+         if (out) return usage(argv[0], JPEGGPU_ERR_PARAM, "Maximum une image en output.");
+         out = a + 10;
+      } else {
+         return usage(argv[0], JPEGGPU_ERR_PARAM, "Pas de paramètre de ce nom");
+      }
+   }
+   if (!in) return usage(argv[0], JPEGGPU_ERR_INVALID_FILE_PATH, "Pas de fichier jpeg/jpg");
+   int n = 0;
+   int rc = jpeggpu_jpeg2ppm(in, out, &n);
+   if (rc) {
+      fprintf(stderr, "Erreur %d : %s\n", rc, jpeggpu_last_error());   // print_erreur, src/erreur.c:7-10
+      return rc > 0 ? rc : 1;
+   }
+   return 0;
+}

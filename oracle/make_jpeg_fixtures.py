@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/jpeg/: real JPEG files + what the REFERENCE does with them.
+
+TEST INFRASTRUCTURE ONLY (runs in the build container, where /root/reference and oracle/_ref exist).
+
+  * inputs: Pillow-encoded baseline / progressive files (gray, 4:4:4, 4:2:2, 4:2:0; odd sizes; default
+    and optimised Huffman tables; comments), deliberately damaged variants of them, and the data
+    files of the reference's own header test (test/test_file/*.jp*g -- data, not source);
+  * expectations: exit status of oracle/_ref/jpeg2ppm_sans_opt (= the erreur_code_t, src/jpeg2ppm.c:70-133)
+    and the SHA-256 of every image it wrote (one per scan for progressive files), plus the codes
+    test/entete_test.c:338-378 expects for the header fixtures.
+
+Damaged inputs on which the reference crashes, hangs or reads out of bounds are dropped: there is no
+reference behaviour to match.
+"""
+import hashlib
+import io
+import json
+import os
+import resource
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+from PIL import Image
+
+HERE = os.path.dirname(os.path.realpath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("JPEG_REF_DIR", "/root/reference")
+BIN = os.path.join(HERE, "_ref", "jpeg2ppm_sans_opt")
+ASAN = os.path.join(HERE, "_ref", "jpeg2ppm_asan")
+OUT = os.path.join(ROOT, "tests", "golden", "jpeg")
+
+# test/entete_test.c:338-378
+ENTETE_EXPECT = {
+    "invader_bad_entete_jfif.jpeg": "ERR_NO_JFIF", "invader_bad_entete_vjfif0.jpeg": "ERR_JFIF_VERSION",
+    "invader_bad_entete_vjfif1.jpeg": "ERR_JFIF_VERSION", "invader_bad_entete_sof0_p.jpeg": "ERR_SOF_PRECISION",
+    "invader_bad_entete_dqt_p.jpeg": "ERR_DQT_PRECISION", "invader_bad_entete_dht_dc2.jpeg": "ERR_HUFF_ID",
+    "invader_bad_entete_dht_dc3.jpeg": "ERR_HUFF_ID", "invader_bad_entete_dht_ac2.jpeg": "ERR_HUFF_ID",
+    "invader_bad_entete_dht_ac3.jpeg": "ERR_HUFF_ID", "invader_bad_entete_baseline_sos_idht_dc.jpeg": "ERR_HUFF_ID",
+    "invader_bad_entete_baseline_sos_idht_ac.jpeg": "ERR_HUFF_ID", "invader_bad_entete_baseline_sos_ss.jpeg": "ERR_SOS_SS",
+    "invader_bad_entete_baseline_sos_se.jpeg": "ERR_SOS_SE", "invader_bad_entete_baseline_sos_ah.jpeg": "ERR_SOS_AH",
+    "invader_bad_entete_baseline_sos_al.jpeg": "ERR_SOS_AL", "invader_bad_entete_prog_sof2_p.jpg": "ERR_SOF_PRECISION",
+    "invader_bad_entete_prog_sof2_idcomp.jpg": "ERR_SOS_COMP_ID", "invader_bad_entete_prog_sos_ss.jpg": "ERR_SOS_SS",
+    "invader_bad_entete_prog_sos_se.jpg": "ERR_SOS_SE", "invader_bad_entete_prog_sos_ah.jpg": "ERR_SOS_AH",
+    "invader_bad_entete_prog_sos_al.jpg": "ERR_SOS_AL", "invader_bad_entete_eoi_av_sos.jpeg": "ERR_EOI_BEFORE_SOS",
+    "invader_bad_entete_no_eoi.jpeg": "ERR_NO_EOI", "invader_bad_entete_no_soi.jpeg": "ERR_NO_SOI",
+    "invader_bad_entete_sev_soi.jpeg": "ERR_SEVERAL_SOI",
+}
+# include/erreur.h:9-79
+ERR_NAMES = ("SUCCESS ERR_0XFF00 ERR_AC_BAD ERR_DC_BAD ERR_SOF_BAD ERR_HUFF_CODE_1 ERR_DIFF_AH_AL ERR_PARAM ERR_OPT ERR_NO_HT "
+             "ERR_NO_QT ERR_INVALID_FILE_PATH ERR_INVALID_FILE_EXT ERR_NB_COMP ERR_SOF_NON_SUPPORTE ERR_APP0_LEN ERR_NO_APP0 "
+             "ERR_COMP_ID ERR_COM_LEN ERR_DHT_START_0 ERR_DHT_LEN ERR_NO_DHT ERR_DQT_LEN ERR_DQT_PRECISION ERR_DQT_ID ERR_NO_DQT "
+             "ERR_EOI_BEFORE_SOS ERR_NO_EOI ERR_HUFF_BAD ERR_HUFF_ID ERR_HUFF_MORE_256 ERR_JFIF_VERSION ERR_NO_JFIF ERR_MARKER_BAD "
+             "ERR_MARKER_UNKNOWN ERR_SEVERAL_SOF ERR_SOF_PRECISION ERR_SOF_LEN ERR_NO_SOF ERR_SEVERAL_SOI ERR_NO_SOI ERR_SOS_COMP_ID "
+             "ERR_SOS_SS ERR_SOS_SE ERR_SOS_AH ERR_SOS_AL ERR_SOS_NB_COMP ERR_SOS_LEN").split()
+
+
+def picture(w, h, seed, gray=False, noise=18.0):
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    a = np.stack([(x * 5 + y * 3) % 256, (x * x // 7 + y * 2) % 256, (x * 2 + y * y // 5) % 256], -1).astype(np.float64)
+    a += 60 * np.sin(x / 9.0)[..., None] * np.cos(y / 7.0)[..., None]
+    a += rng.normal(0, noise, a.shape)
+    im = Image.fromarray(np.clip(a, 0, 255).astype(np.uint8))
+    return im.convert("L") if gray else im
+
+
+def encode(im, **kw):
+    b = io.BytesIO()
+    im.save(b, "JPEG", **kw)
+    return b.getvalue()
+
+
+def segments(data):
+    """[(marker, start, end)] of the header segments up to and including the first SOS."""
+    out, p = [], 2
+    while p < len(data):
+        assert data[p] == 0xFF
+        m = data[p + 1]
+        ln = (data[p + 2] << 8) | data[p + 3]
+        out.append((m, p, p + 2 + ln))
+        p += 2 + ln
+        if m == 0xDA:
+            break
+    return out
+
+
+def seg_of(data, marker, nth=0):
+    return [s for s in segments(data) if s[0] == marker][nth]
+
+
+def limit():
+    resource.setrlimit(resource.RLIMIT_AS, (2 << 30, 2 << 30))
+    resource.setrlimit(resource.RLIMIT_CORE, (0, 0))
+
+
+def run_reference(data, ext):
+    """-> dict(rc, outputs=[{name, sha256, size}]) or None when the reference crashed / hung."""
+    tmp = tempfile.mkdtemp(prefix="jfix")
+    try:
+        src = os.path.join(tmp, "in" + ext)
+        open(src, "wb").write(data)
+        od = os.path.join(tmp, "o")
+        os.makedirs(od)
+        try:
+            # memory-safety first: an input that makes the reference touch memory it does not own has no
+            # reference behaviour (leaks are not an error here: the reference leaks on every error path)
+            a = subprocess.run([ASAN, "-o", os.path.join(tmp, "asan.pnm"), src], capture_output=True, timeout=60,
+                               env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+            if b"AddressSanitizer" in a.stderr:
+                return None
+            r = subprocess.run([BIN, "-o", os.path.join(od, "x.pnm"), src], capture_output=True, timeout=20, preexec_fn=limit)
+        except subprocess.TimeoutExpired:
+            return None
+        if r.returncode < 0 or r.returncode > 60:
+            return None
+        outs = []
+        for f in sorted(os.listdir(od)):
+            p = os.path.join(od, f)
+            if os.path.islink(p):
+                outs.append({"name": f, "link": os.readlink(p)})
+            else:
+                b = open(p, "rb").read()
+                outs.append({"name": f, "sha256": hashlib.sha256(b).hexdigest(), "size": len(b)})
+        return {"rc": r.returncode, "err": ERR_NAMES[r.returncode] if r.returncode < len(ERR_NAMES) else "?", "outputs": outs}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def main():
+    if not os.path.exists(BIN):
+        sys.exit("build oracle/_ref first (make -C oracle ref)")
+    shutil.rmtree(OUT, ignore_errors=True)
+    os.makedirs(OUT)
+    files = {}
+
+    def add(name, data, note):
+        files[name] = (data, note)
+
+    # ---- well-formed files ------------------------------------------------------------------
+    add("c1_gray_512x512_q90.jpg", encode(picture(512, 512, 1, gray=True, noise=6.0), quality=90), "BASELINE.json configs[0]: 512x512 gray baseline")
+    add("c4_prog422_160x120.jpg", encode(picture(160, 120, 2), quality=85, progressive=True, subsampling=1), "configs[3] in miniature: progressive 4:2:2")
+    k = 10
+    for prog in (False, True):
+        for sub, tag in ((None, "gray"), (0, "444"), (1, "422"), (2, "420")):
+            for (w, h), q, opt in (((61, 47), 80, False), ((17, 9), 95, True), ((8, 8), 50, False), ((35, 70), 30, True)):
+                k += 1
+                im = picture(w, h, k, gray=sub is None)
+                kw = dict(quality=q, progressive=prog, optimize=opt)
+                if sub is not None:
+                    kw["subsampling"] = sub
+                add(f"{'prog' if prog else 'base'}_{tag}_{w}x{h}_q{q}{'_opt' if opt else ''}.jpg", encode(im, **kw), "Pillow")
+    add("base_420_1x1.jpg", encode(picture(1, 1, 90), quality=75, subsampling=2), "smallest image")
+    add("prog_gray_q100_40x24.jpg", encode(picture(40, 24, 91, gray=True), quality=100, progressive=True), "all-ones quantisation table")
+    add("base_444_comment_24x24.jpeg", encode(picture(24, 24, 92), quality=70, subsampling=0, comment=b"bonjour"), "COM segment, .jpeg extension")
+    add("prog_420_128x96_q60.jpg", encode(picture(128, 96, 93), quality=60, progressive=True, subsampling=2), "end-of-band runs over many blocks")
+
+    # ---- the reference's own header fixtures (data files) -------------------------------------
+    tf = os.path.join(REF, "test", "test_file")
+    for f in sorted(os.listdir(tf)):
+        add("ref_" + f, open(os.path.join(tf, f), "rb").read(), "test/test_file/" + f)
+
+    # ---- damaged files --------------------------------------------------------------------------
+    base = encode(picture(40, 24, 100), quality=75, subsampling=2)
+    prog = encode(picture(40, 24, 101), quality=75, subsampling=2, progressive=True)
+
+    def insert_before_sos(d, seg):
+        s = seg_of(d, 0xDA)
+        return d[:s[1]] + seg + d[s[1]:]
+
+    add("bad_dri.jpg", insert_before_sos(base, bytes([0xFF, 0xDD, 0, 4, 0, 8])), "DRI is not a known marker")
+    add("bad_app1.jpg", insert_before_sos(base, bytes([0xFF, 0xE1, 0, 6, 69, 120, 105, 102])), "APP1 is not a known marker")
+    a0 = seg_of(base, 0xE0)
+    add("bad_app0_len.jpg", base[:a0[1] + 2] + bytes([0, 18]) + base[a0[1] + 4:a0[2]] + b"\0\0" + base[a0[2]:], "APP0 length 18")
+    add("bad_no_app0.jpg", base[:a0[1]] + base[a0[2]:], "no APP0")
+    s0 = seg_of(base, 0xC0)
+    add("bad_sof1.jpg", base[:s0[1] + 1] + bytes([0xC1]) + base[s0[1] + 2:], "SOF1")
+    add("bad_sof_len.jpg", base[:s0[1] + 2] + bytes([0, 18]) + base[s0[1] + 4:], "SOF length")
+    add("bad_two_sof.jpg", base[:s0[2]] + base[s0[1]:s0[2]] + base[s0[2]:], "two SOF0")
+    add("bad_sof_comp0.jpg", base[:s0[1] + 10] + bytes([0]) + base[s0[1] + 11:], "component id 0")
+    q0 = seg_of(base, 0xDB)
+    add("bad_dqt_len.jpg", base[:q0[1] + 2] + bytes([0, 68]) + base[q0[1] + 4:], "DQT length")
+    add("bad_dqt_id.jpg", base[:q0[1] + 4] + bytes([7]) + base[q0[1] + 5:], "DQT table id 7")
+    h0 = seg_of(base, 0xC4)
+    add("bad_dht_start.jpg", base[:h0[1] + 4] + bytes([0x40]) + base[h0[1] + 5:], "DHT Tc/Th byte 0x40")
+    add("bad_dht_id.jpg", base[:h0[1] + 4] + bytes([0x05]) + base[h0[1] + 5:], "DHT table id 5")
+    full = bytes([0xFF, 0xC4, 0, 21, 0x00, 2] + [0] * 15 + [0, 1])
+    add("bad_dht_complete.jpg", insert_before_sos(base, full), "complete code: the all-ones code word would be in use")
+    add("bad_dht_len.jpg", base[:h0[1] + 2] + bytes([0, (h0[2] - h0[1] - 2) - 1]) + base[h0[1] + 4:], "DHT length one short")
+    ss = seg_of(base, 0xDA)
+    add("bad_sos_len.jpg", base[:ss[1] + 2] + bytes([0, 11]) + base[ss[1] + 4:], "SOS length")
+    add("bad_sos_comp.jpg", base[:ss[1] + 5] + bytes([9]) + base[ss[1] + 6:], "SOS names an unknown component")
+    add("bad_sos_before_dqt.jpg", base[:q0[1]] + base[ss[1]:], "SOS before DQT/DHT")
+    add("bad_marker.jpg", base[:q0[1]] + bytes([0x12]) + base[q0[1] + 1:], "segment does not start with FF")
+    cut = ss[2] + (len(base) - 2 - ss[2]) // 2
+    add("bad_truncated_scan.jpg", base[:cut] + bytes([0xFF, 0xD9]), "baseline scan cut in the middle")
+    add("bad_rst_in_scan.jpg", base[:cut] + bytes([0xFF, 0xD0]) + base[cut:], "RST0 inside the scan")
+    add("bad_trailing_bytes.jpg", base[:-2] + bytes([0x12, 0x34, 0xFF, 0xD9]), "data bytes after the last MCU")
+    # progressive: cut the third scan, drop the last scan, damage Ah/Al of a refinement scan
+    sos = [i for i in range(len(prog) - 1) if prog[i] == 0xFF and prog[i + 1] == 0xDA]
+    add("bad_prog_truncated.jpg", prog[:sos[2] + 40] + bytes([0xFF, 0xD9]), "third scan cut")
+    add("bad_prog_short.jpg", prog[:sos[4]] + bytes([0xFF, 0xD9]), "file ends after four scans (still valid)")
+    hdr_end = sos[5] + 2 + ((prog[sos[5] + 2] << 8) | prog[sos[5] + 3])
+    add("bad_prog_ah_al.jpg", prog[:hdr_end - 1] + bytes([0x31]) + prog[hdr_end:], "refinement scan with Ah-Al = 2")
+    # random single-bit damage inside the entropy-coded data
+    rng = np.random.default_rng(7)
+    for tag, d, first in (("base", base, ss[2]), ("prog", prog, sos[0] + 14)):
+        for i in range(14):
+            b = bytearray(d)
+            p = int(rng.integers(first, len(d) - 2))
+            b[p] ^= 1 << int(rng.integers(0, 8))
+            add(f"flip_{tag}_{i:02d}.jpg", bytes(b), f"bit flip at byte {p}")
+
+    meta = {}
+    dropped = []
+    for name, (data, note) in files.items():
+        ext = os.path.splitext(name)[1]
+        r = run_reference(data, ext)
+        if r is None:
+            dropped.append(name)
+            continue
+        r["note"] = note
+        r["bytes"] = len(data)
+        if name.startswith("ref_") and name[4:] in ENTETE_EXPECT:
+            r["entete_test_expect"] = ENTETE_EXPECT[name[4:]]
+        meta[name] = r
+        open(os.path.join(OUT, name), "wb").write(data)
+    json.dump({"_doc": "generated by oracle/make_jpeg_fixtures.py from oracle/_ref/jpeg2ppm_sans_opt (-o <dir>/x.pnm <file>)",
+               "files": meta}, open(os.path.join(OUT, "expect.json"), "w"), indent=1, sort_keys=True)
+    total = sum(len(files[n][0]) for n in meta)
+    print(f"{len(meta)} fixtures, {total} bytes; dropped (reference crashed or hung): {dropped}")
+    from collections import Counter
+    print(Counter(m["err"] for m in meta.values()))
+
+
+if __name__ == "__main__":
+    main()

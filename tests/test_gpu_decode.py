@@ -1,0 +1,102 @@
+"""GPU suite for the front end + back end + output stage: real JPEG files
+through the product path (host VLD -> pinned planes -> fused HIP kernel -> PPM/PGM), compared with what
+the reference binary wrote for the same files (tests/golden/jpeg/expect.json) and with the CPU oracle."""
+import hashlib
+import io
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers
+from test_frontend import EXPECT, JDIR, decode_with, expected_images, oracle_backend
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_backend(j, d, mcu_rows):
+    return j.render()
+
+
+@pytest.mark.parametrize("name", sorted(EXPECT))
+def test_scan_by_scan_images_equal_reference(gpu, name):
+    e = EXPECT[name]
+    rc, imgs = decode_with(open(os.path.join(JDIR, name), "rb").read(), gpu_backend)
+    assert rc == e["rc"], (rc, e["err"], gpu.last_error())
+    assert [hashlib.sha256(b).hexdigest() for b in imgs] == expected_images(e)
+
+
+def _check_outputs(outdir, e):
+    got = {}
+    for f in sorted(os.listdir(outdir)):
+        p = os.path.join(outdir, f)
+        got[f] = ("link", os.readlink(p)) if os.path.islink(p) else ("file", hashlib.sha256(open(p, "rb").read()).hexdigest())
+    exp = {o["name"]: (("link", o["link"]) if "link" in o else ("file", o["sha256"])) for o in e["outputs"]}
+    assert got == exp
+
+
+@pytest.mark.parametrize("name", sorted(EXPECT))
+def test_jpeg2ppm_writes_the_same_files(gpu, tmp_path, name):
+    """jpeggpu_jpeg2ppm == main() of the reference: status, file names, bytes, final symbolic link."""
+    from jpeg_decoder_amd import frontend as F
+    e = EXPECT[name]
+    out = tmp_path / "o"
+    out.mkdir()
+    rc = 0
+    try:
+        F.jpeg2ppm(os.path.join(JDIR, name), out / "x.pnm")
+    except gpu.JpegGpuError as err:
+        rc = err.code
+    assert rc == e["rc"], (rc, e["err"], gpu.last_error())
+    _check_outputs(out, e)
+
+
+@pytest.mark.parametrize("name", ["c1_gray_512x512_q90.jpg", "c4_prog422_160x120.jpg", "bad_dri.jpg", "bad_truncated_scan.jpg",
+                                  "bad_prog_truncated.jpg"])
+def test_command_line_driver(gpu, tmp_path, name):
+    exe = os.path.join(helpers.ROOT, "jpeg-decoder_amd", "jpeg2ppm_gpu")
+    assert os.path.exists(exe), "build it with make -C jpeg-decoder_amd/csrc"
+    e = EXPECT[name]
+    out = tmp_path / "o"
+    r = subprocess.run([exe, "-o", str(out / "x.pnm"), os.path.join(JDIR, name)], capture_output=True, timeout=120)
+    assert r.returncode == e["rc"], (r.returncode, r.stderr[-300:])
+    _check_outputs(out, e)
+
+
+def test_default_output_name_next_to_input(gpu, tmp_path):
+    from jpeg_decoder_amd import frontend as F
+    src = tmp_path / "img.jpeg"
+    src.write_bytes(open(os.path.join(helpers.GOLDEN, "shaun_the_sheep.jpeg"), "rb").read())
+    assert F.jpeg2ppm(src) == 1
+    assert (tmp_path / "img.ppm").read_bytes() == open(os.path.join(helpers.GOLDEN, "shaun_the_sheep.ppm"), "rb").read()
+
+
+@pytest.mark.parametrize("size,sub,prog", [((1024, 768), 2, True), ((1500, 1001), 1, True), ((2048, 2048), 0, False),
+                                            ((1920, 1080), 2, False)])
+def test_larger_files_against_cpu_oracle(gpu, size, sub, prog):
+    """Files encoded on the spot (Pillow): every scan's image from the GPU == the CPU oracle's."""
+    Image = pytest.importorskip("PIL.Image")
+    from jpeg_decoder_amd import frontend as F
+    rng = np.random.default_rng(size[0] * 7 + sub)
+    w, h = size
+    y, x = np.mgrid[0:h, 0:w]
+    a = np.stack([(x + y) % 256, (x * 3 + y // 2) % 256, (x // 3 + y * 2) % 256], -1).astype(np.float64)
+    a += rng.normal(0, 12, a.shape)
+    b = io.BytesIO()
+    Image.fromarray(np.clip(a, 0, 255).astype(np.uint8)).save(b, "JPEG", quality=88, subsampling=sub, progressive=prog)
+    j = F.Jpeg(b.getvalue())
+    d = j.desc
+    nscan = 0
+    while not j.eoi:
+        j.decode_scan()
+        nscan += 1
+        got = j.render()
+        if nscan in (1, 2, 6) or j.eoi or not prog:   # the oracle costs ~20 ms/MPix: check a few scans and the last
+            assert np.array_equal(got, oracle_backend(j, d, d.nbmcuV)), nscan
+        last = got
+        if j.eoi:
+            break
+        j.next_header()
+    assert nscan == (10 if prog else 1)
+    assert np.array_equal(last, oracle_backend(j, d, d.nbmcuV))
