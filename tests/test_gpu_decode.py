@@ -100,3 +100,19 @@ def test_larger_files_against_cpu_oracle(gpu, size, sub, prog):
         j.next_header()
     assert nscan == (10 if prog else 1)
     assert np.array_equal(last, oracle_backend(j, d, d.nbmcuV))
+
+
+@pytest.mark.parametrize("name", ["ref_shaun_the_sheep.jpeg", "ref_invader_normal.jpeg", "prog_420_61x47_q80.jpg", "base_gray_35x70_q30_opt.jpg"])
+def test_reference_drivers_linked_against_the_compat_library(gpu, tmp_path, name):
+    """SURVEY 8b, link-compatibility face: the reference's own, unmodified baseline.c / progressive.c /
+    decoder_utils.c objects, linked against libjpeggpu_compat.so (iquant, izz, idct_opt, ycc2rgb_pixel
+    -> one GPU round trip each) instead of iqzz.c / idct_opt.c / ycc2rgb.c, write the files the all-CPU
+    reference wrote.  oracle/_ref/jpeg2ppm_compat is built in the build container (make -C oracle compat)."""
+    exe = os.path.join(helpers.ROOT, "oracle", "_ref", "jpeg2ppm_compat")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/jpeg2ppm_compat was not built")
+    e = EXPECT[name]
+    out = tmp_path / "o"
+    r = subprocess.run([exe, "-o", str(out / "x.pnm"), os.path.join(JDIR, name)], capture_output=True, timeout=110)
+    assert r.returncode == e["rc"], (r.returncode, r.stderr[-300:])
+    _check_outputs(out, e)
