@@ -155,6 +155,15 @@ int jpeggpu_iquant_blocks(jpeggpu_blocl16_t *blocks, size_t n, uint8_t s_start, 
 int jpeggpu_izz_blocks(const jpeggpu_blocl16_t *in, jpeggpu_bloct16_t *out, size_t n);
 /* idct_opt, src/idct_opt.c:93-117.                                                             */
 int jpeggpu_idct_opt_blocks(const jpeggpu_bloct16_t *in, jpeggpu_bloctu8_t *out, size_t n);
+/* idct, src/idct.c:50-71: the slow transform the reference uses under "-f" (direct 64-term sums with
+ * calc_coef's table, :35-48).                                                                   */
+int jpeggpu_idct_blocks(const jpeggpu_bloct16_t *in, jpeggpu_bloctu8_t *out, size_t n);
+/* calc_coef's table [x][y][lambda][mu] as this library builds it (host only; cos/sqrt from libm). */
+void jpeggpu_idct_coef_table(float *out4096);
+/* all_option.idct_fast (src/options.c:76-79, a process-wide option in the reference as well):
+ * 1 (default) = idct_opt, 0 = idct for every later jpeggpu_backend_run* / jpeggpu_jpeg_render call. */
+void jpeggpu_set_idct_fast(int fast);
+int  jpeggpu_get_idct_fast(void);
 /* ycc2rgb_pixel, src/ycc2rgb.c:18-22, over n pixels.                                           */
 int jpeggpu_ycc2rgb_pixels(const uint8_t *y, const uint8_t *cb, const uint8_t *cr,
                            jpeggpu_rgb_t *rgb, size_t n);

@@ -82,6 +82,11 @@ lib.jpeggpu_iquant_blocks.argtypes = [_vp, _sz, C.c_uint8, C.c_uint8, _vp]
 lib.jpeggpu_izz_blocks.argtypes = [_vp, _vp, _sz]
 lib.jpeggpu_idct_opt_blocks.argtypes = [_vp, _vp, _sz]
 lib.jpeggpu_ycc2rgb_pixels.argtypes = [_vp, _vp, _vp, _vp, _sz]
+lib.jpeggpu_idct_blocks.argtypes = [_vp, _vp, _sz]
+lib.jpeggpu_idct_coef_table.argtypes = [_vp]
+lib.jpeggpu_idct_coef_table.restype = None
+lib.jpeggpu_set_idct_fast.argtypes = [C.c_int]
+lib.jpeggpu_set_idct_fast.restype = None
 
 
 def last_error():
@@ -198,6 +203,28 @@ def idct_opt_blocks(blocks):
     out = np.zeros((a.shape[0], 8, 8), dtype=np.uint8)
     _check(lib.jpeggpu_idct_opt_blocks(a.ctypes.data, out.ctypes.data, a.shape[0]))
     return out
+
+
+def idct_blocks(blocks):
+    """idct (src/idct.c:50-71), the slow transform of the reference's -f option."""
+    a = np.ascontiguousarray(blocks, dtype=np.int16).reshape(-1, 8, 8)
+    out = np.zeros((a.shape[0], 8, 8), dtype=np.uint8)
+    _check(lib.jpeggpu_idct_blocks(a.ctypes.data, out.ctypes.data, a.shape[0]))
+    return out
+
+
+def idct_coef_table():
+    t = np.zeros(4096, dtype=np.float32)
+    lib.jpeggpu_idct_coef_table(t.ctypes.data)
+    return t.reshape(8, 8, 8, 8)
+
+
+def set_idct_fast(fast):
+    lib.jpeggpu_set_idct_fast(1 if fast else 0)
+
+
+def get_idct_fast():
+    return bool(lib.jpeggpu_get_idct_fast())
 
 
 def ycc2rgb_pixels(y, cb, cr):

@@ -38,6 +38,9 @@ struct State {
    void *d_in = nullptr;  size_t d_in_cap = 0;
    void *d_out = nullptr; size_t d_out_cap = 0;
    void *h_pin = nullptr; size_t h_pin_cap = 0;
+   // "-f" mode (all_option.idct_fast == 0): calc_coef's table on the device, built on first use
+   bool idct_fast = true;
+   float *d_slow_coef = nullptr;
 };
 State g;
 std::mutex g_mu;
@@ -60,6 +63,34 @@ int grow(void **p, size_t *cap, size_t need, bool pinned) {
    if (pinned) HIP_TRY(hipHostMalloc(p, want, hipHostMallocDefault));
    else HIP_TRY(hipMalloc(p, want));
    *cap = want;
+   return 0;
+}
+
+// calc_coef (src/idct.c:35-48) with f_C (:19-24) and calc_cos (:26-32): the double cosine is stored as
+// float, C(lambda)C(mu) is returned as float, and the three floats are multiplied left to right.
+// cos/sqrt come from the platform's libm, as they do for the reference on the same host.
+void calc_coef_host(float *t) {
+   float cs[8][8];
+   for (int x = 0; x < 8; x++)
+      for (int l = 0; l < 8; l++) cs[x][l] = (float)std::cos((2 * x + 1) * l * 3.14159265358979323846 / 16);
+   const float r2 = (float)(1 / std::sqrt(2.0));
+   for (int x = 0; x < 8; x++)
+      for (int y = 0; y < 8; y++)
+         for (int l = 0; l < 8; l++)
+            for (int m = 0; m < 8; m++) {
+               const float fc = l == 0 ? (m == 0 ? 0.5f : r2) : (m == 0 ? r2 : 1.0f);
+               float v = fc * cs[x][l];
+               v = v * cs[y][m];
+               t[((x * 8 + y) * 8 + l) * 8 + m] = v;
+            }
+}
+
+int ensure_slow_coef() {
+   if (g.d_slow_coef) return 0;
+   static float table[4096];
+   calc_coef_host(table);
+   HIP_TRY(hipMalloc((void **)&g.d_slow_coef, sizeof table));
+   HIP_TRY(hipMemcpy(g.d_slow_coef, table, sizeof table, hipMemcpyHostToDevice));
    return 0;
 }
 
@@ -150,6 +181,7 @@ int run_device(const jpeggpu_frame_desc_t *d, uint32_t nframes, const void *cons
    p.out = d_out; p.out_stride = out_stride; p.out_frame_stride = out_frame_stride;
    if (const char *e = getenv("JPEGGPU_DIAG_PTR")) p.diag = (void *)strtoull(e, nullptr, 0);   // diagnostic builds only
    if (nframes == 0) return 0;
+   if (!g.idct_fast) { int rc = ensure_slow_coef(); if (rc) return rc; p.slow_coef = g.d_slow_coef; }
    if (nframes > 65535 || d->nbmcuV > 65535) return fail(JPEGGPU_ERR_INVALID_ARG, "nframes / nbmcuV above 65535");
    ld.frames = nframes;
    HIP_TRY(launch_backend(p, ld, s));
@@ -190,6 +222,7 @@ void jpeggpu_shutdown(void) {
    if (g.d_in) (void)hipFree(g.d_in);
    if (g.d_out) (void)hipFree(g.d_out);
    if (g.h_pin) (void)hipHostFree(g.h_pin);
+   if (g.d_slow_coef) (void)hipFree(g.d_slow_coef);
    (void)hipStreamDestroy(g.stream);
    g = State();
 }
@@ -304,6 +337,18 @@ int jpeggpu_idct_opt_blocks(const jpeggpu_bloct16_t *in, jpeggpu_bloctu8_t *out,
    if (!in || !out) return fail(JPEGGPU_ERR_INVALID_ARG, "NULL argument");
    return stage_roundtrip(in, n * 128, out, n * 64, [](void *di, void *dout, void *c) { return launch_idct(di, dout, *(size_t *)c, g.stream); }, &n);
 }
+
+int jpeggpu_idct_blocks(const jpeggpu_bloct16_t *in, jpeggpu_bloctu8_t *out, size_t n) {
+   if (n == 0) return 0;
+   if (!in || !out) return fail(JPEGGPU_ERR_INVALID_ARG, "NULL argument");
+   int rc = ensure_init(); if (rc) return rc;
+   { std::lock_guard<std::mutex> lk(g_mu); rc = ensure_slow_coef(); if (rc) return rc; }
+   return stage_roundtrip(in, n * 128, out, n * 64, [](void *di, void *dout, void *c) { return launch_idct_slow(di, dout, *(size_t *)c, g.d_slow_coef, g.stream); }, &n);
+}
+
+void jpeggpu_set_idct_fast(int fast) { g.idct_fast = fast != 0; }
+int jpeggpu_get_idct_fast(void) { return g.idct_fast ? 1 : 0; }
+void jpeggpu_idct_coef_table(float *out4096) { if (out4096) calc_coef_host(out4096); }
 
 int jpeggpu_ycc2rgb_pixels(const uint8_t *y, const uint8_t *cb, const uint8_t *cr, jpeggpu_rgb_t *rgb, size_t n) {
    if (n == 0) return 0;

@@ -1,7 +1,8 @@
 // jpeg2ppm_gpu -- thin command-line driver over jpeggpu_jpeg2ppm: same arguments for input and
 // output file as the reference's jpeg2ppm (src/options.c:58-66: "-o <fichier>" / "--outfile=<fichier>")
 // and the same exit status (the erreur_code_t of the failure, src/jpeg2ppm.c:70-72,93-96,129-133).
-// Everything else of the reference's CLI (timers, verbose, table dumps) is out of scope.
+// "-f" / "--no-fast-idct" selects the slow transform like the reference.  Everything else of the
+// reference's CLI (timers, verbose, table dumps) is out of scope.
 #include <cstdio>
 #include <cstring>
 
@@ -9,7 +10,7 @@
 
 static int usage(const char *exe, int code, const char *why) {
    if (why) fprintf(stderr, "Erreur %d : %s\n", code, why);
-   fprintf(stderr, "Usage : %s [-o <fichier> | --outfile=<fichier>] fichier.jpg|fichier.jpeg\n", exe);
+   fprintf(stderr, "Usage : %s [-f | --no-fast-idct] [-o <fichier> | --outfile=<fichier>] fichier.jpg|fichier.jpeg\n", exe);
    return code;
 }
 
@@ -23,6 +24,8 @@ int main(int argc, char **argv) {
       } else if (strcmp(a, "-h") == 0 || strcmp(a, "--help") == 0) {
          usage(argv[0], 0, nullptr);
          return 0;
+      } else if (strcmp(a, "-f") == 0 || strcmp(a, "--no-fast-idct") == 0) {
+         jpeggpu_set_idct_fast(0);   // set_idct_nofast_param, src/options.c:76-79
       } else if (strcmp(a, "-o") == 0) {
          if (i + 1 >= argc) return usage(argv[0], JPEGGPU_ERR_OPT, "Manque la valeur pour le paramètre 'o'");
          if (out) return usage(argv[0], JPEGGPU_ERR_PARAM, "Maximum une image en output.");

@@ -12,6 +12,7 @@ struct BackendParams {
    const void *coef[3];            // device plane pointers of frame 0 (blocl16_t arrays)
    void *out;                      // device raster of frame 0
    void *diag;                     // JM_DIAG_STAMP builds only: 5 x uint64 phase-time accumulators (else NULL)
+   const float *slow_coef;         // "-f" mode: calc_coef's table [x][y][lambda][mu] (src/idct.c:35-48); NULL = idct_opt
    uint64_t coef_frame_stride[3];  // bytes between consecutive frames' planes
    uint64_t out_stride;            // bytes between raster rows
    uint64_t out_frame_stride;      // bytes between consecutive frames' rasters
@@ -40,6 +41,7 @@ hipError_t launch_backend(const BackendParams &p, const LaunchDims &d, hipStream
 hipError_t launch_iquant(void *d_blocks, size_t n, int s_start, int s_end, const uint32_t qt_packed[32], hipStream_t s);
 hipError_t launch_izz(const void *d_in, void *d_out, size_t n, hipStream_t s);
 hipError_t launch_idct(const void *d_in, void *d_out, size_t n, hipStream_t s);
+hipError_t launch_idct_slow(const void *d_in, void *d_out, size_t n, const float *d_coef, hipStream_t s);
 hipError_t launch_ycc2rgb(const uint8_t *d_y, const uint8_t *d_cb, const uint8_t *d_cr, uint8_t *d_rgb, size_t n, hipStream_t s);
 
 }  // namespace jpeggpu_k

@@ -227,6 +227,43 @@ __device__ __forceinline__ void transform_block(const BackendParams &p, const Bl
    for (int r = 0; r < 8; r++) *reinterpret_cast<uint2 *>(plane + r * pitch) = rows[r];
 }
 
+// "-f": the direct transform idct (src/idct.c:50-71) instead of idct_opt.  Per sample (x, y) a 64-term
+// sum in (lambda, mu) order, product and accumulation rounded separately in fp32, then *0.25, +128,
+// clamp, truncate.  The table index is wave-uniform.  Not a fast path: 8192 fp32 operations per block.
+__device__ __forceinline__ uint32_t slow_sample(const float (&m)[8][8], const float *__restrict__ c) {
+   float sum = 0.0f;
+#pragma unroll
+   for (int l = 0; l < 8; l++)
+#pragma unroll
+      for (int mu = 0; mu < 8; mu++) {
+         float val = c[l * 8 + mu];
+         val *= m[l][mu];
+         sum += val;
+      }
+   sum *= 0.25f;
+   return to_u8(sum);
+}
+
+__device__ __forceinline__ void transform_block_slow(const BackendParams &p, const BlockCtx &k, const uint4 (&v)[8], const uint32_t *qt_lds,
+                                                  uint8_t *lds) {
+   float m[8][8];
+   const uint4 *q4 = reinterpret_cast<const uint4 *>(qt_lds + k.idq * 32);
+   uint32_t zw[32], qw[32];
+#pragma unroll
+   for (int i = 0; i < 8; i++) {
+      uint4 q = make_uint4(0x00010001u, 0x00010001u, 0x00010001u, 0x00010001u);
+      if (p.apply_iquant) q = q4[i];
+      zw[4 * i] = v[i].x; zw[4 * i + 1] = v[i].y; zw[4 * i + 2] = v[i].z; zw[4 * i + 3] = v[i].w;
+      qw[4 * i] = q.x; qw[4 * i + 1] = q.y; qw[4 * i + 2] = q.z; qw[4 * i + 3] = q.w;
+   }
+   dequant_izz(zw, qw, m);   // m[lambda][mu] = bloct16_t.data[lambda][mu] (src/iqzz.c:23)
+   const uint32_t pitch = k.bw * 8;
+   uint8_t *plane = lds + k.plane_off + (k.by * 8) * pitch + k.bxl * 8;
+#pragma unroll 1
+   for (uint32_t xy = 0; xy < 64; xy++)   // res->data[x][y]: column x, row y
+      plane[(xy & 7) * pitch + (xy >> 3)] = (uint8_t)slow_sample(m, p.slow_coef + xy * 64);
+}
+
 __device__ __forceinline__ const uint8_t *record_ptr(const BlockCtx &k, uint32_t tile, uint32_t m, uint32_t frame, bool &in_plane) {
    const uint32_t col = tile * k.bw + k.bxl;
    in_plane = col < k.nbH;
@@ -237,8 +274,8 @@ __device__ __forceinline__ const uint8_t *record_ptr(const BlockCtx &k, uint32_t
 // One workgroup = one tile of T MCUs of one MCU row, one thread per 8x8 block.  Each lane pulls its
 // own 128-byte record with 8 x 16-byte loads (one full cache line per lane; tools/ubench_read.hip:
 // 6.4-6.7 TB/s, no slower than lane-coalesced loads and no LDS staging or extra barrier needed).
-template <int HFC, int VFC>   // chroma factors; 0 = generic path (any factors, any component)
-__global__ void __launch_bounds__(256, JM_WAVES_PER_EU) backend_kernel(const BackendParams p) {
+template <int HFC, int VFC, bool SLOW>   // chroma factors; 0 = generic path (any factors, any component)
+__device__ __forceinline__ void backend_body(const BackendParams &p) {
    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
    const uint32_t tid = threadIdx.x, nt = blockDim.x;
    const uint32_t tile = blockIdx.x, m = blockIdx.y, frame = blockIdx.z;
@@ -271,7 +308,10 @@ __global__ void __launch_bounds__(256, JM_WAVES_PER_EU) backend_kernel(const Bac
    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
    const long long ts1 = __builtin_amdgcn_s_memtime();
 #endif
-   if (active) transform_block(p, k, v, qt_lds, lds);
+   if (active) {
+      if constexpr (SLOW) transform_block_slow(p, k, v, qt_lds, lds);
+      else transform_block(p, k, v, qt_lds, lds);
+   }
 #if defined(JM_DIAG_STAMP)
    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
    const long long ts2 = __builtin_amdgcn_s_memtime();
@@ -296,8 +336,15 @@ __global__ void __launch_bounds__(256, JM_WAVES_PER_EU) backend_kernel(const Bac
 #endif
 }
 
+template <int HFC, int VFC>
+__global__ void __launch_bounds__(256, JM_WAVES_PER_EU) backend_kernel(const BackendParams p) { backend_body<HFC, VFC, false>(p); }
+
+// the "-f" variant: generic pixel phase, no occupancy target (the direct transform keeps the block in 64 VGPRs)
+__global__ void __launch_bounds__(256) backend_kernel_slow(const BackendParams p) { backend_body<0, 0, true>(p); }
+
 typedef void (*BackendFn)(const BackendParams);
 static BackendFn pick_kernel(const BackendParams &p) {
+   if (p.slow_coef) return (BackendFn)backend_kernel_slow;
 #define JM_PICK(H, V) ((BackendFn)backend_kernel<H, V>)
    if (p.nbcomp == 3 && p.hf[0] == 1 && p.vf[0] == 1 && p.hf[1] == p.hf[2] && p.vf[1] == p.vf[2]) {
       const uint32_t h = p.hf[1], v = p.vf[1];
@@ -363,6 +410,20 @@ __global__ void idct_kernel(const int16_t *in, uint8_t *out, size_t n) {
    }
 }
 
+__global__ void __launch_bounds__(64) idct_slow_kernel(const int16_t *in, uint8_t *out, size_t n, const float *__restrict__ coef) {
+   size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // one block per thread
+   if (b >= n) return;
+   float m[8][8];
+   const int16_t *src = in + b * 64;
+#pragma unroll
+   for (int l = 0; l < 8; l++)
+#pragma unroll
+      for (int mu = 0; mu < 8; mu++) m[l][mu] = (float)src[l * 8 + mu];
+   uint8_t *dst = out + b * 64;
+#pragma unroll 1
+   for (uint32_t xy = 0; xy < 64; xy++) dst[xy] = (uint8_t)slow_sample(m, coef + xy * 64);   // data[x][y]
+}
+
 __global__ void ycc2rgb_kernel(const uint8_t *y, const uint8_t *cb, const uint8_t *cr, uint8_t *rgb, size_t n) {
    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
    if (i >= n) return;
@@ -386,6 +447,11 @@ hipError_t launch_izz(const void *d_in, void *d_out, size_t n, hipStream_t s) {
 hipError_t launch_idct(const void *d_in, void *d_out, size_t n, hipStream_t s) {
    if (n == 0) return hipSuccess;
    hipLaunchKernelGGL(idct_kernel, dim3(nblocks(n, 64)), dim3(64), 0, s, static_cast<const int16_t *>(d_in), static_cast<uint8_t *>(d_out), n);
+   return hipGetLastError();
+}
+hipError_t launch_idct_slow(const void *d_in, void *d_out, size_t n, const float *d_coef, hipStream_t s) {
+   if (n == 0) return hipSuccess;
+   hipLaunchKernelGGL(idct_slow_kernel, dim3(nblocks(n, 64)), dim3(64), 0, s, static_cast<const int16_t *>(d_in), static_cast<uint8_t *>(d_out), n, d_coef);
    return hipGetLastError();
 }
 hipError_t launch_ycc2rgb(const uint8_t *d_y, const uint8_t *d_cb, const uint8_t *d_cr, uint8_t *d_rgb, size_t n, hipStream_t s) {

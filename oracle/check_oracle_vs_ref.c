@@ -15,6 +15,8 @@ void ref_iquant_blocks(jpeggpu_blocl16_t *, size_t, int, int, const jpeggpu_qtab
 void ref_izz_blocks(const jpeggpu_blocl16_t *, jpeggpu_bloct16_t *, size_t);
 void ref_idct_opt_blocks(const jpeggpu_bloct16_t *, jpeggpu_bloctu8_t *, size_t);
 void ref_ycc2rgb_pixels(const uint8_t *, const uint8_t *, const uint8_t *, jpeggpu_rgb_t *, size_t);
+void ref_idct_blocks(const jpeggpu_bloct16_t *, jpeggpu_bloctu8_t *, size_t);
+void ref_idct_coef(float *);
 
 static int fails = 0;
 #define CHECK(cond, ...) do { if (!(cond)) { fails++; printf("FAILED: " __VA_ARGS__); printf("\n"); } } while (0)
@@ -34,6 +36,12 @@ static void check_stage_blocks(size_t n, uint64_t seed, int kind, const jpeggpu_
    for (size_t i = 0; i < n; i++) bad += memcmp(&pa[i], &pb[i], 64) != 0;
    CHECK(bad == 0, "idct_opt kind %d: %zu of %zu blocks differ", kind, bad, n);
    printf("stage chain kind %d: %zu blocks, %zu differing\n", kind, n, bad);
+   /* the slow transform (src/idct.c) on a sixteenth of the blocks (it is 8x slower) */
+   size_t ns = n / 16, bads = 0;
+   oracle_idct_blocks(za, pa, ns); ref_idct_blocks(zb, pb, ns);
+   for (size_t i = 0; i < ns; i++) bads += memcmp(&pa[i], &pb[i], 64) != 0;
+   CHECK(bads == 0, "idct (slow) kind %d: %zu of %zu blocks differ", kind, bads, ns);
+   printf("slow idct kind %d: %zu blocks, %zu differing\n", kind, ns, bads);
    free(a); free(b); free(za); free(zb); free(pa); free(pb);
 }
 
@@ -61,7 +69,15 @@ static void check_frame(int w, int h, int nc, const int hs[3], const int vs[3], 
    free(oa); free(ob);
 }
 
+static void check_coef_table(void) {
+   static float a[8][8][8][8], b[4096];
+   oracle_idct_coef(a); ref_idct_coef(b);
+   CHECK(!memcmp(a, b, sizeof b), "calc_coef table differs");
+   printf("calc_coef table: %s\n", memcmp(a, b, sizeof b) ? "DIFFERENT" : "identical (4096 floats)");
+}
+
 int main(int argc, char **argv) {
+   check_coef_table();
    size_t nmil = argc > 1 ? (size_t)atoi(argv[1]) : 4;
    /* quantisation tables: a JPEG-like ramp and a full-range one (exercises the int16 wrap) */
    jpeggpu_qtable_t qa, qb, qc;

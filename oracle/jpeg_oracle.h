@@ -24,6 +24,13 @@ void oracle_iquant(int16_t zz[64], int s_start, int s_end, const uint16_t q[64])
 void oracle_izz(const int16_t zz[64], int16_t out[8][8]);
 void oracle_idct_opt(const int16_t in[8][8], uint8_t out[8][8]);
 void oracle_ycc2rgb_pixel(uint8_t y, uint8_t cb, uint8_t cr, uint8_t rgb[3]);
+/* The slow transform selected by "-f" (src/idct.c:35-71): direct 64-term sum per sample with the
+ * coefficient table of calc_coef (cos/sqrt of the platform's libm, like the reference).          */
+void oracle_idct_coef(float coef[8][8][8][8]);
+void oracle_idct(const int16_t in[8][8], uint8_t out[8][8]);
+void oracle_idct_blocks(const jpeggpu_bloct16_t *in, jpeggpu_bloctu8_t *out, size_t n);
+/* all_option.idct_fast (src/options.c:76-79): 1 = idct_opt (default), 0 = idct, for oracle_backend_*. */
+void oracle_set_idct_fast(int fast);
 
 /* n-item forms (same signatures as the jpeggpu_*_blocks stage entries, minus the GPU). */
 void oracle_iquant_blocks(jpeggpu_blocl16_t *blocks, size_t n, int s_start, int s_end,

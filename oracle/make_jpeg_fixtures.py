@@ -97,7 +97,7 @@ def limit():
     resource.setrlimit(resource.RLIMIT_CORE, (0, 0))
 
 
-def run_reference(data, ext):
+def run_reference(data, ext, extra=()):
     """-> dict(rc, outputs=[{name, sha256, size}]) or None when the reference crashed / hung."""
     tmp = tempfile.mkdtemp(prefix="jfix")
     try:
@@ -108,11 +108,11 @@ def run_reference(data, ext):
         try:
             # memory-safety first: an input that makes the reference touch memory it does not own has no
             # reference behaviour (leaks are not an error here: the reference leaks on every error path)
-            a = subprocess.run([ASAN, "-o", os.path.join(tmp, "asan.pnm"), src], capture_output=True, timeout=60,
+            a = subprocess.run([ASAN, *extra, "-o", os.path.join(tmp, "asan.pnm"), src], capture_output=True, timeout=60,
                                env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
             if b"AddressSanitizer" in a.stderr:
                 return None
-            r = subprocess.run([BIN, "-o", os.path.join(od, "x.pnm"), src], capture_output=True, timeout=20, preexec_fn=limit)
+            r = subprocess.run([BIN, *extra, "-o", os.path.join(od, "x.pnm"), src], capture_output=True, timeout=20, preexec_fn=limit)
         except subprocess.TimeoutExpired:
             return None
         if r.returncode < 0 or r.returncode > 60:
@@ -226,10 +226,24 @@ def main():
         r["bytes"] = len(data)
         if name.startswith("ref_") and name[4:] in ENTETE_EXPECT:
             r["entete_test_expect"] = ENTETE_EXPECT[name[4:]]
+        if r["rc"] == 0 and not name.startswith(("flip_", "bad_")):
+            # the same file under "-f" (slow idct, src/idct.c): row f4
+            rs = run_reference(data, ext, extra=("-f",))
+            if rs is not None and rs["rc"] == 0:
+                r["outputs_slow"] = rs["outputs"]
         meta[name] = r
         open(os.path.join(OUT, name), "wb").write(data)
     json.dump({"_doc": "generated by oracle/make_jpeg_fixtures.py from oracle/_ref/jpeg2ppm_sans_opt (-o <dir>/x.pnm <file>)",
                "files": meta}, open(os.path.join(OUT, "expect.json"), "w"), indent=1, sort_keys=True)
+    # stage vectors of the slow transform and its coefficient table, from the reference objects
+    sys.path.insert(0, ROOT)
+    from oracle import pyoracle
+    ref = pyoracle.load_ref("strict")
+    rng = np.random.default_rng(11)
+    blocks = np.concatenate([rng.integers(-1024, 1025, size=(96, 8, 8)), rng.integers(-32768, 32768, size=(64, 8, 8)),
+                             rng.integers(0, 256, size=(64, 8, 8)), np.zeros((1, 8, 8), dtype=np.int64)]).astype(np.int16)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "idct_slow_vectors.npz"), blocks=blocks, out=ref.idct_blocks(blocks),
+                        coef=ref.idct_coef())
     total = sum(len(files[n][0]) for n in meta)
     print(f"{len(meta)} fixtures, {total} bytes; dropped (reference crashed or hung): {dropped}")
     from collections import Counter

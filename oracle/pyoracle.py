@@ -41,6 +41,9 @@ class _Backend:
         getattr(lib, prefix + "izz_blocks").argtypes = [_vp, _vp, _sz]
         getattr(lib, prefix + "idct_opt_blocks").argtypes = [_vp, _vp, _sz]
         getattr(lib, prefix + "ycc2rgb_pixels").argtypes = [_vp, _vp, _vp, _vp, _sz]
+        getattr(lib, prefix + "idct_blocks").argtypes = [_vp, _vp, _sz]
+        getattr(lib, prefix + "idct_coef").argtypes = [_vp]
+        getattr(lib, prefix + "set_idct_fast").argtypes = [C.c_int]
 
     def backend_run(self, desc, coef, qtables, mcu_rows=None):
         d = FrameDesc.from_buffer_copy(bytes(desc))
@@ -81,6 +84,22 @@ class _Backend:
         out = np.zeros((a.shape[0], 8, 8), dtype=np.uint8)
         getattr(self.lib, self.p + "idct_opt_blocks")(a.ctypes.data, out.ctypes.data, a.shape[0])
         return out
+
+    def idct_blocks(self, blocks):
+        """The slow transform of -f (src/idct.c:50-71)."""
+        a = np.ascontiguousarray(blocks, dtype=np.int16).reshape(-1, 8, 8)
+        out = np.zeros((a.shape[0], 8, 8), dtype=np.uint8)
+        getattr(self.lib, self.p + "idct_blocks")(a.ctypes.data, out.ctypes.data, a.shape[0])
+        return out
+
+    def idct_coef(self):
+        t = np.zeros((8, 8, 8, 8), dtype=np.float32)
+        getattr(self.lib, self.p + "idct_coef")(t.ctypes.data)
+        return t
+
+    def set_idct_fast(self, fast):
+        """all_option.idct_fast for backend_run: True = idct_opt, False = idct."""
+        getattr(self.lib, self.p + "set_idct_fast")(1 if fast else 0)
 
     def ycc2rgb_pixels(self, y, cb, cr):
         y, cb, cr = (np.ascontiguousarray(v, dtype=np.uint8).reshape(-1) for v in (y, cb, cr))

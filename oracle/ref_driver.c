@@ -17,6 +17,7 @@
 #include <img.h>
 #include <iqzz.h>
 #include <idct_opt.h>
+#include <idct.h>
 #include <ycc2rgb.h>
 #include <decoder_utils.h>
 #include <entete.h>
@@ -27,6 +28,22 @@
 #include "../include/jpeggpu.h"
 
 extern all_option_t all_option;
+
+/* all_option.idct_fast for the harness (src/baseline.c:190-191, src/progressive.c:284-285) */
+static int g_ref_idct_fast = 1;
+static float g_ref_coef[8][8][8][8];
+static int g_ref_coef_ready = 0;
+void ref_set_idct_fast(int fast) { g_ref_idct_fast = fast != 0; }
+void ref_idct_coef(float *out4096) { calc_coef((float(*)[8][8][8])out4096); }
+static bloctu8_t *ref_transform(bloct16_t *zz) {
+   if (g_ref_idct_fast) return idct_opt(zz);
+   if (!g_ref_coef_ready) { calc_coef(g_ref_coef); g_ref_coef_ready = 1; }
+   return idct(zz, g_ref_coef);
+}
+void ref_idct_blocks(const jpeggpu_bloct16_t *in, jpeggpu_bloctu8_t *out, size_t n) {
+   if (!g_ref_coef_ready) { calc_coef(g_ref_coef); g_ref_coef_ready = 1; }
+   for (size_t i = 0; i < n; i++) { bloctu8_t *r = idct((bloct16_t *)&in[i], g_ref_coef); memcpy(&out[i], r, sizeof *r); free(r); }
+}
 
 /* Reference back end over full-frame planes; same contract as jpeggpu_backend_run.
  * MCU rows [m0, m1).  Mirrors the loop structure of src/progressive.c:257-312.                 */
@@ -71,7 +88,7 @@ int ref_backend_rows(const jpeggpu_frame_desc_t *d, const jpeggpu_blocl16_t *con
                memcpy(q.data, coef[c][((size_t)m * d->comp[c].vs + by) * nbH + bx].data, sizeof q.data);
                if (d->apply_iquant) iquant(&q, 0, 63, (qtable_t *)qtables[d->comp[c].idq]);
                bloct16_t *zz = izz(&q);
-               bloctu8_t *px = idct_opt(zz);
+               bloctu8_t *px = ref_transform(zz);
                free(zz);
                free(ycc[c][by * nbH + bx]);
                ycc[c][by * nbH + bx] = px;
