@@ -31,6 +31,10 @@ static size_t check_blocks(size_t n, uint64_t seed, int kind, const jpeggpu_qtab
       dequant_izz_pk(zw, qw, p1);           // the packed form the fused kernel uses
       idct_block_pk(p1, rows2);
       if (memcmp(rows, rows2, sizeof rows)) { bad++; continue; }
+      f32x2 p2[4][8]; uint2 rows3[8];
+      dequant_izz_rp(zw, qw, p2);           // pass 2 packed within a row (pairing (0,4)(2,6)(1,7)(3,5))
+      idct_block_rp(p2, rows3);
+      if (memcmp(rows, rows3, sizeof rows)) { bad++; continue; }
       for (int r = 0; r < 8; r++)
          for (int c = 0; c < 8; c++) {
             uint8_t got = (uint8_t)(((c < 4 ? rows[r].x : rows[r].y) >> (8 * (c & 3))) & 0xFF);

@@ -193,6 +193,85 @@ JM_HD void idct_block_pk(float (&m)[8][8], uint2 (&row)[8]) {
    idct_block_pk(p1, row);
 }
 
+// ---- pass 2 packed WITHIN a row ------------------------------------------------------------
+// Pass 1 may pair any two columns in one packed register, so it pairs (0,4) (2,6) (1,7) (3,5): for a
+// row those pairs are exactly the operand pairs of the first butterflies/rotations of idct_opt_1D
+// ({t0,t1} {t2,t3} {t7,t4} {t5,t6} after its reorder), and every later stage can be kept in pairs too
+// with the half-swaps expressed as VOP3P op_sel modifiers -- no transposes, no moves.  Each element
+// sees the same IEEE operations in the same order as in idct8<float>.
+//   jm_sumdiff(p)      = { p.x + p.y, p.x - p.y }
+//   jm_cross_a(q2, q3) = { q2.y + q3.y, q2.x - q3.x }
+//   jm_add_sub(a, b)   = { a.x + b.x, a.y - b.y }
+//   jm_swap_mul(a, k)  = { a.y * k,  a.x * k }
+//   jm_sub_add(a, b)   = { a.x - b.x, a.y + b.y }
+//   jm_add_swap(a, b)  = { a.x + b.y, a.y + b.x }      jm_sub_swap(a, b) = { a.x - b.y, a.y - b.x }
+#if defined(__HIP_DEVICE_COMPILE__)
+#define JM_PK2(name, mnem, mods)                                                                   \
+   __device__ __forceinline__ f32x2 name(f32x2 a, f32x2 b) {                                        \
+      f32x2 d;                                                                                     \
+      asm(mnem " %0, %1, %2 " mods : "=v"(d) : "v"(a), "v"(b));                                    \
+      return d;                                                                                    \
+   }
+JM_PK2(jm_sumdiff2, "v_pk_add_f32", "op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]")
+JM_PK2(jm_cross_a, "v_pk_add_f32", "op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[0,1]")
+JM_PK2(jm_add_sub, "v_pk_add_f32", "neg_hi:[0,1]")
+JM_PK2(jm_sub_add, "v_pk_add_f32", "neg_lo:[0,1]")
+JM_PK2(jm_add_swap, "v_pk_add_f32", "op_sel:[0,1] op_sel_hi:[1,0]")
+JM_PK2(jm_sub_swap, "v_pk_add_f32", "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]")
+JM_PK2(jm_swap_mul2, "v_pk_mul_f32", "op_sel:[1,0] op_sel_hi:[0,1]")
+#undef JM_PK2
+__device__ __forceinline__ f32x2 jm_sumdiff(f32x2 p) { return jm_sumdiff2(p, p); }
+__device__ __forceinline__ f32x2 jm_swap_mul(f32x2 a, float k) { return jm_swap_mul2(a, f32x2{k, k}); }
+#else
+JM_HD f32x2 jm_sumdiff(f32x2 p) { return f32x2{p.x + p.y, p.x - p.y}; }
+JM_HD f32x2 jm_cross_a(f32x2 a, f32x2 b) { return f32x2{a.y + b.y, a.x - b.x}; }
+JM_HD f32x2 jm_add_sub(f32x2 a, f32x2 b) { return f32x2{a.x + b.x, a.y - b.y}; }
+JM_HD f32x2 jm_sub_add(f32x2 a, f32x2 b) { return f32x2{a.x - b.x, a.y + b.y}; }
+JM_HD f32x2 jm_add_swap(f32x2 a, f32x2 b) { return f32x2{a.x + b.y, a.y + b.x}; }
+JM_HD f32x2 jm_sub_swap(f32x2 a, f32x2 b) { return f32x2{a.x - b.y, a.y - b.x}; }
+JM_HD f32x2 jm_swap_mul(f32x2 a, float k) { return f32x2{a.y * k, a.x * k}; }
+#endif
+
+// One row of pass 2.  In: P0 = {v0,v4}, P1 = {v2,v6}, P2 = {v1,v7}, P3 = {v3,v5} (natural coefficient
+// indices).  Out: o[0..7] in sample order.
+JM_HD void idct8_row_pk(f32x2 P0, f32x2 P1, f32x2 P2, f32x2 P3, float (&o)[8]) {
+   // stage 4 inverse: X(7,4) on {t7,t4}; iO on {t5,t6}
+   const f32x2 Q2 = jm_sumdiff(P2);                               // {t7', t4'}
+   const f32x2 Q3 = mul_hl(P3, JM_RH2, JM_RL2);                   // {t5', t6'}
+   // stage 3 inverse: X(0,1); C(2,3,k); X(4,6); X(7,5)
+   const f32x2 S01 = jm_sumdiff(P0);                              // {t0', t1'}
+   const f32x2 XY = mul_hl(P1, JM_KH2, JM_KL2);                   // {x, y}
+   const f32x2 S23 = jm_sub_add(XY * (f32x2)JM_C6, jm_swap_mul(XY, JM_S6));   // {x*C6 - y*S6, y*C6 + x*S6}
+   const f32x2 A = jm_cross_a(Q2, Q3);                            // {t4'+t6', t7'-t5'} = {t4'', t5''}
+   const f32x2 B = jm_add_sub(Q2, Q3);                            // {t7'+t5', t4'-t6'} = {t7'', t6''}
+   // stage 2 inverse: X(0,3) X(1,2); C(4,7,C3,S3) C(5,6,C1,S1)
+   const f32x2 U = jm_add_swap(S01, S23);                         // {t0+t3, t1+t2}
+   const f32x2 V = jm_sub_swap(S01, S23);                         // {t0-t3, t1-t2} = {t3'', t2''}
+   const f32x2 Cc = f32x2{JM_C3, JM_C1}, Sc = f32x2{JM_S3, JM_S1};
+   const f32x2 W45 = A * Cc - B * Sc;                             // {t4*C3 - t7*S3, t5*C1 - t6*S1}
+   const f32x2 W76 = B * Cc + A * Sc;                             // {t7*C3 + t4*S3, t6*C1 + t5*S1}
+   // stage 1 inverse + normalisation
+   const f32x2 O01 = mul_hl(U + W76, JM_SH8, JM_SL8);             // {o0, o1}
+   const f32x2 O76 = mul_hl(U - W76, JM_SH8, JM_SL8);             // {o7, o6}
+   const f32x2 O32 = mul_hl(V + W45, JM_SH8, JM_SL8);             // {o3, o2}
+   const f32x2 O45 = mul_hl(V - W45, JM_SH8, JM_SL8);             // {o4, o5}
+   o[0] = O01.x; o[1] = O01.y; o[2] = O32.y; o[3] = O32.x; o[4] = O45.x; o[5] = O45.y; o[6] = O76.y; o[7] = O76.x;
+}
+
+// Column -> (pair, half) of the pass-1 pairing (0,4) (2,6) (1,7) (3,5).
+#define JM_RP_PAIR { 0, 2, 1, 3, 0, 3, 1, 2 }
+#define JM_RP_HALF { 0, 0, 0, 0, 1, 1, 1, 1 }
+JM_HD void idct_block_rp(f32x2 (&p1)[4][8], uint2 (&row)[8]) {
+#pragma unroll
+   for (int cp = 0; cp < 4; cp++) idct8(p1[cp]);
+#pragma unroll
+   for (int r = 0; r < 8; r++) {
+      float u[8];
+      idct8_row_pk(p1[0][r], p1[1][r], p1[2][r], p1[3][r], u);
+      row[r] = pack_row(u);
+   }
+}
+
 // iquant (src/iqzz.c:12): product narrowed to int16 (wraps), then the int16 -> float conversion of
 // src/idct_opt.c:97.
 JM_HD float dequant_to_float(int zz, uint32_t q) {
@@ -218,6 +297,22 @@ JM_HD void dequant_izz(const uint32_t (&zw)[32], const uint32_t (&qw)[32], float
       jm_us2 pr = a * b;
       m[ZC[2 * i]][ZR[2 * i]] = (float)(int)(short)pr.x;
       m[ZC[2 * i + 1]][ZR[2 * i + 1]] = (float)(int)(short)pr.y;
+   }
+}
+
+// dequant_izz straight into the pairing of idct_block_rp.
+JM_HD void dequant_izz_rp(const uint32_t (&zw)[32], const uint32_t (&qw)[32], f32x2 (&p1)[4][8]) {
+   constexpr uint8_t ZR[64] = JM_ZZ_ROWS;
+   constexpr uint8_t ZC[64] = JM_ZZ_COLS;
+   constexpr uint8_t PP[8] = JM_RP_PAIR;
+   constexpr uint8_t PH[8] = JM_RP_HALF;
+#pragma unroll
+   for (int i = 0; i < 32; i++) {
+      jm_us2 a = __builtin_bit_cast(jm_us2, zw[i]), b = __builtin_bit_cast(jm_us2, qw[i]);
+      jm_us2 pr = a * b;
+      const float f0 = (float)(int)(short)pr.x, f1 = (float)(int)(short)pr.y;
+      if (PH[ZC[2 * i]]) p1[PP[ZC[2 * i]]][ZR[2 * i]].y = f0; else p1[PP[ZC[2 * i]]][ZR[2 * i]].x = f0;
+      if (PH[ZC[2 * i + 1]]) p1[PP[ZC[2 * i + 1]]][ZR[2 * i + 1]].y = f1; else p1[PP[ZC[2 * i + 1]]][ZR[2 * i + 1]].x = f1;
    }
 }
 
