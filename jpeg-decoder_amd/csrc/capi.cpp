@@ -182,7 +182,7 @@ int run_device(const jpeggpu_frame_desc_t *d, uint32_t nframes, const void *cons
    if (const char *e = getenv("JPEGGPU_DIAG_PTR")) p.diag = (void *)strtoull(e, nullptr, 0);   // diagnostic builds only
    if (nframes == 0) return 0;
    if (!g.idct_fast) { int rc = ensure_slow_coef(); if (rc) return rc; p.slow_coef = g.d_slow_coef; }
-   if ((uint64_t)nframes * d->nbmcuV * ld.tiles_per_row > 0x7FFFFFFFull) return fail(JPEGGPU_ERR_INVALID_ARG, "more than 2^31 tiles in one launch");
+   if (nframes > 65535 || d->nbmcuV > 65535) return fail(JPEGGPU_ERR_INVALID_ARG, "nframes / nbmcuV above 65535");
    ld.frames = nframes;
    HIP_TRY(launch_backend(p, ld, s));
    return 0;

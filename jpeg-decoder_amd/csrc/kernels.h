@@ -12,7 +12,6 @@ struct BackendParams {
    const void *coef[3];            // device plane pointers of frame 0 (blocl16_t arrays)
    void *out;                      // device raster of frame 0
    void *diag;                     // JM_DIAG_STAMP builds only: 5 x uint64 phase-time accumulators (else NULL)
-   uint32_t grid_tiles, grid_rows, grid_frames;   // tile grid (tiles per MCU row, MCU rows, frames), flattened onto blockIdx.x
    const float *slow_coef;         // "-f" mode: calc_coef's table [x][y][lambda][mu] (src/idct.c:35-48); NULL = idct_opt
    uint64_t coef_frame_stride[3];  // bytes between consecutive frames' planes
    uint64_t out_stride;            // bytes between raster rows

@@ -219,7 +219,7 @@ __device__ __forceinline__ void transform_block(const BackendParams &p, const Bl
 #if defined(JM_IDCT_HY)
       dequant_izz_pk(zw, qw, mtx);
 #else
-      dequant_izz_rp(zw, qw, mtx);
+      dequant_izz_rp(zw, qw, mtx);   // pass-1 pairing (0,4)(2,6)(1,7)(3,5): pass 2 stays packed within a row
 #endif
 #if defined(JM_DIAG_NOIDCT)
 #pragma unroll
@@ -288,35 +288,20 @@ __device__ __forceinline__ const uint8_t *record_ptr(const BlockCtx &k, uint32_t
 // One workgroup = one tile of T MCUs of one MCU row, one thread per 8x8 block.  Each lane pulls its
 // own 128-byte record with 8 x 16-byte loads (one full cache line per lane; tools/ubench_read.hip:
 // 6.4-6.7 TB/s, no slower than lane-coalesced loads and no LDS staging or extra barrier needed).
-// Workgroup-wide barrier that orders LDS traffic only: global loads issued before it stay in flight.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// Tiles walked by one workgroup.  Measured on MI355X (same-run A/B, c2..c5): 1 is fastest; 2, 4 and 8
-// tiles with the next tile's records requested behind the current transform are 3 %, 8 % and 16 % slower
-// (the hardware already overlaps phases across the 8 resident workgroups of a CU).
-#ifndef JM_TILES_PER_GROUP
-#define JM_TILES_PER_GROUP 1
-#endif
 template <int HFC, int VFC, bool SLOW>   // chroma factors; 0 = generic path (any factors, any component)
 __device__ __forceinline__ void backend_body(const BackendParams &p) {
    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-   const uint32_t tid0 = threadIdx.x, nt = blockDim.x;
+   const uint32_t tid = threadIdx.x, nt = blockDim.x;
+   const uint32_t tile = blockIdx.x, m = blockIdx.y, frame = blockIdx.z;
+#if defined(JM_DIAG_STAMP)
+   const long long ts0 = __builtin_amdgcn_s_memtime();
+   const long long tr0 = __builtin_amdgcn_s_memrealtime();
+#endif
    uint32_t *qt_lds = reinterpret_cast<uint32_t *>(lds + (size_t)nt * 64);
-   if (p.apply_iquant && tid0 < 128) qt_lds[tid0] = p.qt[tid0 >> 5][tid0 & 31];
-   if (p.apply_iquant && nt < 128) qt_lds[tid0 + 64] = p.qt[(tid0 >> 5) + 2][tid0 & 31];   // nt == 64
-   // One workgroup walks JM_TILES_PER_GROUP tiles of the flattened (frame, MCU row, tile) grid, gridDim.x
-   // apart, in straight-line code.  The records of tile i+1 are requested right after tile i's
-   // transform has consumed its registers, so they are in flight during the barrier, the pixel phase
-   // and its stores instead of being waited for at the head of a fresh workgroup.
-   const uint32_t total = p.grid_tiles * p.grid_rows * p.grid_frames, stride = gridDim.x;
-   uint4 v[JM_TILES_PER_GROUP][8];
-   auto fetch = [&](uint4 (&r)[8], uint32_t tt) {
-      uint32_t tid = tid0;
-      asm volatile("" : "+v"(tid));      // per-tile context is re-derived, not kept live across tiles
-      const bool active = tid < p.B;
-      const BlockCtx k = decode_block(p, active ? tid : 0);
-      const uint32_t tile = tt % p.grid_tiles, rest = tt / p.grid_tiles;
-      const uint32_t m = rest % p.grid_rows, frame = rest / p.grid_rows;
+   const bool active = tid < p.B;
+   const BlockCtx k = decode_block(p, active ? tid : 0);
+   uint4 v[8];
+   {
       bool in_plane;
       const uint4 *src = reinterpret_cast<const uint4 *>(record_ptr(k, tile, m, frame, in_plane));
 #if defined(JM_DIAG_NOLOAD)
@@ -324,61 +309,40 @@ __device__ __forceinline__ void backend_body(const BackendParams &p) {
 #endif
       if (active && in_plane) {
 #pragma unroll
-         for (int i = 0; i < 8; i++) r[i] = src[i];   // NOT non-temporal: a lane's 8 loads share one line (nt: 1.6x slower)
+         for (int i = 0; i < 8; i++) v[i] = src[i];   // NOT non-temporal: a lane's 8 loads share one line (nt: 1.6x slower)
       } else {
 #pragma unroll
-         for (int i = 0; i < 8; i++) r[i] = make_uint4(0, 0, 0, 0);
+         for (int i = 0; i < 8; i++) v[i] = make_uint4(0, 0, 0, 0);
       }
-   };
-   if (blockIdx.x >= total) return;
-#if defined(JM_DIAG_STAMP)   // per-wave phase clocks (tools/stamp.py); meaningful with one tile per group
-   const long long ts0 = __builtin_amdgcn_s_memtime();
-   const long long tr0 = __builtin_amdgcn_s_memrealtime();
-   long long ts1 = 0, ts2 = 0, ts3 = 0;
-#endif
-   fetch(v[0], blockIdx.x);
-#pragma unroll
-   for (int i = 0; i < JM_TILES_PER_GROUP; i++) {
-      const uint32_t t = blockIdx.x + i * stride;
-      if (t >= total) break;
-      lds_barrier();     // quantisation tables visible; the previous tile's pixel phase has left the planes
+   }
+   if (p.apply_iquant && tid < 128) qt_lds[tid] = p.qt[tid >> 5][tid & 31];
+   if (p.apply_iquant && nt < 128) qt_lds[tid + 64] = p.qt[(tid >> 5) + 2][tid & 31];   // nt == 64
+   __syncthreads();
 #if defined(JM_DIAG_STAMP)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      ts1 = __builtin_amdgcn_s_memtime();
+   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+   const long long ts1 = __builtin_amdgcn_s_memtime();
 #endif
-      {
-         uint32_t tid = tid0;
-         asm volatile("" : "+v"(tid));
-         const bool active = tid < p.B;
-         const BlockCtx k = decode_block(p, active ? tid : 0);
-         if (active) {
-            if constexpr (SLOW) transform_block_slow(p, k, v[i], qt_lds, lds);
-            else transform_block(p, k, v[i], qt_lds, lds);
-         }
-      }
-      if (i + 1 < JM_TILES_PER_GROUP && t + stride < total) fetch(v[(i + 1) % JM_TILES_PER_GROUP], t + stride);
+   if (active) {
+      if constexpr (SLOW) transform_block_slow(p, k, v, qt_lds, lds);
+      else transform_block(p, k, v, qt_lds, lds);
+   }
 #if defined(JM_DIAG_STAMP)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      ts2 = __builtin_amdgcn_s_memtime();
+   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+   const long long ts2 = __builtin_amdgcn_s_memtime();
 #endif
-      lds_barrier();
+   __syncthreads();
 #if defined(JM_DIAG_STAMP)
-      ts3 = __builtin_amdgcn_s_memtime();
+   const long long ts3 = __builtin_amdgcn_s_memtime();
 #endif
 #if !defined(JM_DIAG_NOPHASE2)
-      {
-         uint32_t tid = tid0;
-         asm volatile("" : "+v"(tid));
-         const uint32_t tile = t % p.grid_tiles, rest = t / p.grid_tiles;
-         pixel_phase<HFC, VFC>(p, lds, tid, nt, tile, rest % p.grid_rows, rest / p.grid_rows);
-      }
+   pixel_phase<HFC, VFC>(p, lds, tid, nt, tile, m, frame);
 #endif
-   }
 #if defined(JM_DIAG_STAMP)
    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
    const long long ts4 = __builtin_amdgcn_s_memtime();
-   if ((tid0 & 63) == 0 && p.diag) {
-      unsigned long long *slot = (unsigned long long *)p.diag + ((size_t)blockIdx.x * (nt >> 6) + (tid0 >> 6)) * 8;
+   if ((tid & 63) == 0 && p.diag) {
+      const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      unsigned long long *slot = (unsigned long long *)p.diag + (wg * (nt >> 6) + (tid >> 6)) * 8;
       slot[0] = (unsigned long long)(ts1 - ts0); slot[1] = (unsigned long long)(ts2 - ts1); slot[2] = (unsigned long long)(ts3 - ts2);
       slot[3] = (unsigned long long)(ts4 - ts3); slot[4] = (unsigned long long)(__builtin_amdgcn_s_memrealtime() - tr0);
       slot[5] = (unsigned long long)tr0;
@@ -407,14 +371,8 @@ static BackendFn pick_kernel(const BackendParams &p) {
 #undef JM_PICK
 }
 
-hipError_t launch_backend(const BackendParams &p0, const LaunchDims &d, hipStream_t s) {
-   BackendParams p = p0;
-   p.grid_tiles = d.tiles_per_row; p.grid_rows = d.mcu_rows; p.grid_frames = d.frames;
-   const uint64_t total = (uint64_t)d.tiles_per_row * d.mcu_rows * d.frames;
-   if (total == 0 || total > 0xFFFFFFFFull) return hipErrorInvalidValue;
-   // every workgroup walks JM_TILES_PER_GROUP tiles, <groups> apart
-   const uint64_t groups = (total + JM_TILES_PER_GROUP - 1) / JM_TILES_PER_GROUP;
-   dim3 grid((unsigned)groups), block(d.threads);
+hipError_t launch_backend(const BackendParams &p, const LaunchDims &d, hipStream_t s) {
+   dim3 grid(d.tiles_per_row, d.mcu_rows, d.frames), block(d.threads);
    BackendFn k = pick_kernel(p);
    if (d.lds_bytes > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d.lds_bytes);
