@@ -100,6 +100,38 @@ int  jpeggpu_out_file_name(const char *filepath, const char *outfile, uint8_t nb
  * (src/progressive.c:332-343).  *nb_images receives the number of images written.                */
 int  jpeggpu_jpeg2ppm(const char *filepath, const char *outfile, int *nb_images);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Batches of independent images (BASELINE.json configs[4]: thousands of same-size files)        */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct jpeggpu_blob_s { const uint8_t *data; size_t len; } jpeggpu_blob_t;
+
+typedef struct jpeggpu_batch_stats_s {
+   double seconds;            /* wall time of the call                                            */
+   double vld_seconds;        /* entropy decoding, summed over the host threads                   */
+   uint32_t images_ok;        /* images with status 0                                             */
+   uint32_t threads;          /* host threads used                                                */
+   uint32_t chunk_frames;     /* frames per GPU launch                                            */
+   uint32_t chunks;           /* launches                                                         */
+   uint32_t output_registered;/* 1: rasters pinned in place (no staging copy)                     */
+} jpeggpu_batch_stats_t;
+
+/* Decodes <n> JPEG files of identical geometry (width, height, components, sampling factors; tables
+ * may differ from file to file) into rasters + i*raster_frame_stride (each laid out like the output of
+ * jpeggpu_backend_run; stride 0 = packed).  No counterpart in the reference, which decodes one file per
+ * process; every image goes through the same front end and the same kernel as jpeggpu_jpeg2ppm (for
+ * progressive files only the image after the last scan is produced).
+ *
+ * Host threads run the header parser and Huffman VLD of different images in parallel, writing
+ * dequantised coefficients (iquant as in decode_bloc_baseline, src/baseline.c:66) straight into a pinned
+ * chunk buffer; each chunk is one hipMemcpyAsync, one jpeggpu_backend_run_batch_device launch
+ * (apply_iquant = 0) and one copy back, double-buffered so that the GPU works on chunk k while the
+ * threads decode chunk k+1.  status[i] (may be NULL) receives each image's status; a failed image
+ * leaves its raster undefined.  Returns 0 when the batch ran (even if some images failed), a negative
+ * status when it could not.  nthreads <= 0: min(16, hardware threads).                             */
+int jpeggpu_decode_batch(const jpeggpu_blob_t *jpegs, size_t n, uint8_t *rasters, size_t raster_frame_stride,
+                         int nthreads, int *status, jpeggpu_frame_desc_t *desc_out, jpeggpu_batch_stats_t *stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -461,7 +461,7 @@ static inline int dc_first(BitReader &br, const HuffTable &t, unsigned al, int16
 }
 
 // decode_coef_AC_first_scan in a loop (src/vld.c:124-174, :307-327)
-int Decoder::ac_first(BitReader &br, const HuffTable &t, int16_t *blk, uint16_t &skip) {
+int Decoder::ac_first(BitReader &br, const HuffTable &t, int16_t *blk, uint16_t &skip, const uint16_t *q) {
    unsigned idx = ss;
    skip = 0;
    while (idx <= se) {
@@ -484,6 +484,7 @@ int Decoder::ac_first(BitReader &br, const HuffTable &t, int16_t *blk, uint16_t 
       if (!read_index(br, gamma, v)) return fail(JPEGGPU_ERR_0XFF00, "%s", kMsgFF);
       if (idx > 63) return fail(JPEGGPU_ERR_UNSUPPORTED, "coefficient AC hors du bloc (indice %u)", idx);   // the reference writes past the block
       blk[idx] = (int16_t)(magnitude_value(gamma, v) * (1 << al));
+      if (q) blk[idx] = (int16_t)(blk[idx] * (int)q[idx]);   // iquant, src/iqzz.c:12 (only non-zero coefficients change)
       idx++;
    }
    return 0;
@@ -593,9 +594,11 @@ int Decoder::scan_baseline(BitReader &br) {
                   if (rc) return rc;
                   blk[0] = (int16_t)(blk[0] + pred[c]);
                   pred[c] = blk[0];
+                  const uint16_t *q = dequant_on_store ? qt[ci.idq] : nullptr;
+                  if (q) blk[0] = (int16_t)(blk[0] * (int)q[0]);
                   uint16_t skip;
                   ss = 1;
-                  rc = ac_first(br, hac[ci.idhac], blk, skip);
+                  rc = ac_first(br, hac[ci.idhac], blk, skip, q);
                   ss = ss0;
                   if (rc) return rc;
                }
@@ -684,6 +687,17 @@ int Decoder::scan_progressive_ac(BitReader &br) {
       }
    dirty[c] = true;
    return 0;
+}
+
+void Decoder::dequantise_planes() {
+   for (int c = 0; c < nbcomp && c < 3; c++) {
+      if (!plane[c] || comp[c].idq > 3 || !qt_present[comp[c].idq]) continue;
+      const uint16_t *q = qt[comp[c].idq];
+      int16_t *p = plane[c];
+      const size_t nb = plane_blocks(c);
+      for (size_t b = 0; b < nb; b++, p += 64)
+         for (int i = 0; i < 64; i++) p[i] = (int16_t)(p[i] * (int)q[i]);
+   }
 }
 
 int Decoder::decode_scan() {

@@ -61,6 +61,7 @@ struct Decoder {
    int16_t *plane[3] = { nullptr, nullptr, nullptr };   // zeroed full-frame planes, owned by the caller (pinned when a GPU is present)
    bool dirty[3] = { false, false, false };
    unsigned scans_decoded = 0;
+   bool dequant_on_store = false;     // baseline only: store coef * qtable (int16 wrap) like decode_bloc_baseline's iquant (src/baseline.c:66)
    uint32_t mcu_rows_done = 0;        // complete MCU rows of the last baseline scan (partial output on error)
    std::vector<uint8_t> scanbuf;
    std::string err;
@@ -68,6 +69,7 @@ struct Decoder {
    int open();                 // decode_entete(first pass)
    int next_header();          // decode_entete(later pass)
    int decode_scan();          // entropy-decode the pending scan + finir_octet
+   void dequantise_planes();   // iquant(0, 63) over every block with the current tables (dense; progressive batch path)
    int get_composante(unsigned k) const;
    size_t plane_blocks(int c) const { return (size_t)nbmcuH * comp[c].hs * (size_t)nbmcuV * comp[c].vs; }
 
@@ -92,7 +94,7 @@ struct Decoder {
    int scan_baseline(BitReader &br);
    int scan_progressive_dc(BitReader &br);
    int scan_progressive_ac(BitReader &br);
-   int ac_first(BitReader &br, const HuffTable &t, int16_t *blk, uint16_t &skip);
+   int ac_first(BitReader &br, const HuffTable &t, int16_t *blk, uint16_t &skip, const uint16_t *q = nullptr);
    int ac_refine(BitReader &br, const HuffTable &t, int16_t *blk, uint16_t &skip);
    int refine_to_band_end(BitReader &br, int16_t *blk, unsigned idx);
 };

@@ -145,3 +145,48 @@ def jpeg2ppm(filepath, outfile=None):
     n = C.c_int(0)
     B._check(lib.jpeggpu_jpeg2ppm(str(filepath).encode(), None if outfile is None else str(outfile).encode(), C.byref(n)))
     return n.value
+
+
+class Blob(C.Structure):
+    _fields_ = [("data", _vp), ("len", _sz)]
+
+
+class BatchStats(C.Structure):
+    _fields_ = [("seconds", C.c_double), ("vld_seconds", C.c_double), ("images_ok", C.c_uint32), ("threads", C.c_uint32),
+                ("chunk_frames", C.c_uint32), ("chunks", C.c_uint32), ("output_registered", C.c_uint32)]
+
+
+lib.jpeggpu_decode_batch.argtypes = [C.POINTER(Blob), _sz, _vp, _sz, C.c_int, C.POINTER(C.c_int), C.POINTER(B.FrameDesc),
+                                     C.POINTER(BatchStats)]
+
+
+def decode_batch(files, nthreads=0, out=None):
+    """jpeggpu_decode_batch: <files> = sequence of bytes objects holding same-geometry JPEG files.
+    -> (rasters (n, rows, row_bytes) uint8, status list, FrameDesc, BatchStats)."""
+    n = len(files)
+    bufs = [np.frombuffer(f, dtype=np.uint8) for f in files]
+    blobs = (Blob * max(n, 1))()
+    for i, a in enumerate(bufs):
+        blobs[i].data, blobs[i].len = a.ctypes.data, a.size
+    # geometry first (host only), to size the output
+    probe = None
+    for f in files:
+        try:
+            probe = Jpeg(f)
+            break
+        except B.JpegGpuError:
+            continue
+    if probe is None:
+        # let the library report the error of the first file
+        d, st, stats = B.FrameDesc(), (C.c_int * max(n, 1))(), BatchStats()
+        dummy = np.zeros(16, dtype=np.uint8)
+        B._check(lib.jpeggpu_decode_batch(blobs, n, dummy.ctypes.data, 0, nthreads, st, C.byref(d), C.byref(stats)))
+        return np.zeros((n, 0, 0), np.uint8), list(st)[:n], d, stats
+    d0 = probe.desc
+    rows, rb = B.raster_rows(d0), B.raster_row_bytes(d0)
+    probe.close()
+    if out is None:
+        out = np.empty((n, rows, rb), dtype=np.uint8)
+    d, st, stats = B.FrameDesc(), (C.c_int * max(n, 1))(), BatchStats()
+    B._check(lib.jpeggpu_decode_batch(blobs, n, out.ctypes.data, 0, nthreads, st, C.byref(d), C.byref(stats)))
+    return out, list(st)[:n], d, stats
