@@ -159,6 +159,10 @@ void plan_backend(const jpeggpu_frame_desc_t *d, const jpeggpu_qtable_t *const q
    ld.mcu_rows = d->nbmcuV;
    ld.threads = (p.B + 63) / 64 * 64;                 // one thread per block
    ld.lds_bytes = (size_t)ld.threads * 64 + 512;
+   if (const char *e = getenv("JPEGGPU_DIAG_LDS_BYTES")) {   // diagnostic: larger allocation = fewer resident workgroups per CU
+      size_t v = (size_t)atol(e);
+      if (v > ld.lds_bytes && v <= 64 * 1024) ld.lds_bytes = v;
+   }
 }
 
 int run_device(const jpeggpu_frame_desc_t *d, uint32_t nframes, const void *const d_coef[3], const size_t cfs[3],
