@@ -211,3 +211,21 @@ def test_render_needs_a_gpu():
     with pytest.raises(jg.JpegGpuError) as e:
         j.render()
     assert e.value.code in (jg.ERR_NO_DEVICE, jg.ERR_HIP)
+
+
+def test_front_end_survives_damaged_files(tmp_path):
+    """tools/fuzz_frontend.cpp under AddressSanitizer + UBSan: 40 000 randomly damaged variants of the
+    fixtures, every scan decoded -- no invalid access, no hang, only status codes."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = tmp_path / "fuzz"
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                           "-I" + os.path.join(helpers.ROOT, "jpeg-decoder_amd", "csrc"), "-I" + os.path.join(helpers.ROOT, "include"),
+                           "-o", str(exe), os.path.join(helpers.ROOT, "tools", "fuzz_frontend.cpp"),
+                           os.path.join(helpers.ROOT, "jpeg-decoder_amd", "csrc", "frontend.cpp")])
+    r = subprocess.run([str(exe), JDIR, "40000"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="halt_on_error=1"))
+    assert r.returncode == 0 and "iterations 40000" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
