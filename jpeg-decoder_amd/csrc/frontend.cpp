@@ -460,16 +460,40 @@ static inline int dc_first(BitReader &br, const HuffTable &t, unsigned al, int16
    return 0;
 }
 
-// decode_coef_AC_first_scan in a loop (src/vld.c:124-174, :307-327)
+// decode_coef_AC_first_scan in a loop (src/vld.c:124-174, :307-327).  One 64-bit window per coefficient
+// serves the Huffman code (<= 16 bits) and the value bits (<= 10) that follow it.
 int Decoder::ac_first(BitReader &br, const HuffTable &t, int16_t *blk, uint16_t &skip, const uint16_t *q) {
    unsigned idx = ss;
    skip = 0;
-   while (idx <= se) {
-      int s = huff_symbol(br, t, nullptr);
-      if (s < 0) return s == -2 ? fail(JPEGGPU_ERR_HUFF_BAD, "[DHT] table de Huffman AC vide") : fail(JPEGGPU_ERR_0XFF00, "%s", kMsgFF);
+   const uint8_t *const buf = br.buf;
+   const uint64_t limit = br.limit;
+   uint64_t pos = br.pos;
+   const unsigned last = se;
+   while (idx <= last) {
+      uint64_t w;
+      memcpy(&w, buf + (pos >> 3), 8);
+      w = __builtin_bswap64(w) << (pos & 7);                 // >= 57 valid bits
+      const unsigned f = t.fast[w >> 55];
+      unsigned len;
+      int s;
+      if (f) {
+         len = f >> 8;
+         s = (int)(f & 0xFF);
+      } else {
+         const uint32_t w16 = (uint32_t)(w >> 48);
+         int nd = t.deep[w >> 55];
+         len = 9;
+         if (t.nodes[nd].child[0] < 0) { br.pos = pos; return fail(JPEGGPU_ERR_HUFF_BAD, "[DHT] table de Huffman AC vide"); }
+         while (t.nodes[nd].child[0] >= 0 && len < 16) { nd = t.nodes[nd].child[(w16 >> (15 - len)) & 1]; len++; }
+         if (t.nodes[nd].child[0] >= 0) { br.pos = pos; return fail(JPEGGPU_ERR_HUFF_BAD, "[DHT] table de Huffman AC vide"); }
+         s = t.nodes[nd].sym;
+      }
+      pos += len;
+      if (pos >= limit) { br.pos = pos; return fail(JPEGGPU_ERR_0XFF00, "%s", kMsgFF); }
       if (s == 0xF0) { idx += 16; continue; }
-      unsigned alpha = (unsigned)s >> 4, gamma = (unsigned)s & 15;
+      const unsigned alpha = (unsigned)s >> 4, gamma = (unsigned)s & 15;
       if (gamma == 0) {
+         br.pos = pos;
          if (alpha == 0) { skip = 1; return 0; }
          if (num_sof == 0) return fail(JPEGGPU_ERR_AC_BAD, "Code invalide pour AC (%x) car mode baseline", s);
          if (alpha > 14) return fail(JPEGGPU_ERR_AC_BAD, "EOB%d interdit (max = 14)", alpha);
@@ -479,14 +503,17 @@ int Decoder::ac_first(BitReader &br, const HuffTable &t, int16_t *blk, uint16_t 
          return 0;
       }
       idx += alpha;
-      if (gamma > 10) return fail(JPEGGPU_ERR_AC_BAD, "La magnitude doit être inférieur ou égale à 10");
-      uint32_t v;
-      if (!read_index(br, gamma, v)) return fail(JPEGGPU_ERR_0XFF00, "%s", kMsgFF);
-      if (idx > 63) return fail(JPEGGPU_ERR_UNSUPPORTED, "coefficient AC hors du bloc (indice %u)", idx);   // the reference writes past the block
-      blk[idx] = (int16_t)(magnitude_value(gamma, v) * (1 << al));
-      if (q) blk[idx] = (int16_t)(blk[idx] * (int)q[idx]);   // iquant, src/iqzz.c:12 (only non-zero coefficients change)
+      if (gamma > 10) { br.pos = pos; return fail(JPEGGPU_ERR_AC_BAD, "La magnitude doit être inférieur ou égale à 10"); }
+      const uint32_t v = (uint32_t)((w << len) >> (64 - gamma));   // len + gamma <= 26 bits of the window
+      pos += gamma;
+      if (pos >= limit) { br.pos = pos; return fail(JPEGGPU_ERR_0XFF00, "%s", kMsgFF); }
+      if (idx > 63) { br.pos = pos; return fail(JPEGGPU_ERR_UNSUPPORTED, "coefficient AC hors du bloc (indice %u)", idx); }   // the reference writes past the block
+      int c = magnitude_value(gamma, v) * (1 << al);
+      if (q) c = (int16_t)c * (int)q[idx];                         // iquant, src/iqzz.c:12 (only non-zero coefficients change)
+      blk[idx] = (int16_t)c;
       idx++;
    }
+   br.pos = pos;
    return 0;
 }
 
