@@ -173,6 +173,7 @@ extern "C" int jpeggpu_decode_batch(const jpeggpu_blob_t *jpegs, size_t n, uint8
    // chunk: about 256 MiB of coefficients, at least 2 images per thread, at most the batch
    size_t F = (size_t(256) << 20) / (in_bytes > out_bytes ? in_bytes : out_bytes);
    if (F < 2 * T) F = 2 * T;
+   F = (F + T - 1) / T * T;                 // whole rounds of the thread pool
    if (F > 4096) F = 4096;
    if (F > n) F = n;
    const size_t nchunks = (n + F - 1) / F;
@@ -201,27 +202,40 @@ extern "C" int jpeggpu_decode_batch(const jpeggpu_blob_t *jpegs, size_t n, uint8
          (void)hipGetLastError();
          for (int b = 0; b < nbuf; b++) HIP_TRYB(hipHostMalloc((void **)&R.h_out[b], F * out_bytes, hipHostMallocDefault));
       }
-      auto collect = [&](int b) -> int {   // wait for buffer b's launch and, when staging, copy its rasters out
-         if (!queued[b]) return 0;
-         HIP_TRYB(hipEventSynchronize(R.ev_done[b]));
-         if (!registered) {
-            const size_t base = queued_base[b];
-            const uint8_t *src = R.h_out[b];
-            pool.run(queued_cnt[b], [&](size_t i) { memcpy(rasters + (base + i) * raster_frame_stride, src + i * out_bytes, out_bytes); });
-         }
-         queued[b] = false;
-         return 0;
-      };
-      for (size_t k = 0; k < nchunks; k++) {
+      // Iteration k runs ONE fork-join over the pool: the decode tasks of chunk k followed by the copy-out
+      // tasks of chunk k-1 (staging only).  The copy tasks sit at the end of the list, so the threads reach
+      // them when the GPU has long finished chunk k-1; the first one to get there waits for its event.
+      std::atomic<int> hip_error{ 0 };
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      for (size_t k = 0; k <= nchunks; k++) {
          const int b = (int)(k % nbuf);
-         const size_t base = k * F, cnt = (base + F <= n) ? F : n - base;
-         int r0 = collect(b);             // buffer b: previous launch finished (its pinned input is free again)
-         if (r0) return r0;
+         const bool have_chunk = k < nchunks;
+         const size_t base = k * F, cnt = have_chunk ? ((base + F <= n) ? F : n - base) : 0;
+         // the buffers of slot b are free once the launch that used them last (chunk k - nbuf) has finished
+         if (have_chunk && queued[b] && (registered || nbuf == 1)) {
+            HIP_TRYB(hipEventSynchronize(R.ev_done[b]));
+            queued[b] = false;
+         }
+         // copy-out of the previous chunk (staging): slot pb
+         const int pb = (int)((k + nbuf - 1) % nbuf);
+         const bool copy_prev = !registered && k >= 1 && queued[pb] && !(nbuf == 1 && have_chunk);
+         const size_t pbase = queued_base[pb], pcnt = copy_prev ? queued_cnt[pb] : 0;
+         const uint8_t *psrc = R.h_out[pb];
+         hipEvent_t pev = R.ev_done[pb];
          // plane c of frame i of the chunk: h_in[b] + off[c] + i * plane_bytes[c]
          size_t off[3] = { 0, 0, 0 };
          for (int c = 1; c < desc.nbcomp; c++) off[c] = off[c - 1] + F * plane_bytes[c - 1];
          uint8_t *hin = R.h_in[b];
-         pool.run(cnt, [&](size_t i) {
+         pool.run(cnt + pcnt, [&](size_t task) {
+            if (task >= cnt) {                          // ---- copy-out of image (task - cnt) of the previous chunk
+               const size_t i = task - cnt;
+               (void)hipSetDevice(dev);                 // worker threads start on device 0
+               if (hipEventSynchronize(pev) != hipSuccess) { hip_error.store(1); return; }
+               memcpy(rasters + (pbase + i) * raster_frame_stride, psrc + i * out_bytes, out_bytes);
+               return;
+            }
+            const size_t i = task;                      // ---- entropy decoding of image i of this chunk
             const auto t0 = clk::now();
             jpegfe::Decoder d;
             d.data = jpegs[base + i].data; d.len = jpegs[base + i].len;
@@ -244,6 +258,9 @@ extern "C" int jpeggpu_decode_batch(const jpeggpu_blob_t *jpegs, size_t n, uint8
             if (r == 0) ok.fetch_add(1);
             vld_ns.fetch_add((uint64_t)(secs(t0, clk::now()) * 1e9));
          });
+         if (hip_error.load()) return bfail(JPEGGPU_ERR_HIP, "hipEventSynchronize a échoué dans un thread de copie");
+         if (copy_prev) queued[pb] = false;
+         if (!have_chunk) break;
          const void *dc[3] = { nullptr, nullptr, nullptr };
          size_t cfs[3] = { 0, 0, 0 };
          for (int c = 0; c < desc.nbcomp; c++) { dc[c] = (char *)R.d_in[b] + off[c]; cfs[c] = plane_bytes[c]; }
@@ -256,7 +273,17 @@ extern "C" int jpeggpu_decode_batch(const jpeggpu_blob_t *jpegs, size_t n, uint8
          HIP_TRYB(hipEventRecord(R.ev_done[b], R.st[b]));
          queued[b] = true; queued_base[b] = base; queued_cnt[b] = cnt;
       }
-      for (int b = 0; b < nbuf; b++) { int r2 = collect(b); if (r2) return r2; }
+      // whatever is still queued (registered output: the last launches; staging with one buffer: its copy-out)
+      for (int b2 = 0; b2 < nbuf; b2++) {
+         if (!queued[b2]) continue;
+         HIP_TRYB(hipEventSynchronize(R.ev_done[b2]));
+         if (!registered) {
+            const size_t qb = queued_base[b2];
+            const uint8_t *src = R.h_out[b2];
+            pool.run(queued_cnt[b2], [&](size_t i) { memcpy(rasters + (qb + i) * raster_frame_stride, src + i * out_bytes, out_bytes); });
+         }
+         queued[b2] = false;
+      }
       return 0;
    };
    rc = pipeline();
