@@ -89,6 +89,9 @@ int  jpeggpu_jpeg_render(jpeggpu_jpeg_t *j, uint8_t *out, size_t out_stride);
 /* Output stage: "P5\n"|"P6\n", "%d %d\n", "255\n" (src/baseline.c:121-130, src/progressive.c:241-244)
  * followed by ALL raster rows, padded ones included (src/decoder_utils.c:51,68).                 */
 int  jpeggpu_write_pnm(const char *path, const jpeggpu_frame_desc_t *desc, const uint8_t *raster, size_t stride);
+/* Same with an explicit row count: rows = desc->height gives a file whose payload matches its header
+ * (the reference never does that: it always writes the padded rows, src/decoder_utils.c:51,68).      */
+int  jpeggpu_write_pnm_rows(const char *path, const jpeggpu_frame_desc_t *desc, const uint8_t *raster, size_t stride, size_t rows);
 
 /* out_file_name (src/utils.c:56-90): <outfile or input path> with "-<nb>" inserted before the
  * extension when nb != 0; without outfile the extension becomes .pgm/.ppm.  Returns the length

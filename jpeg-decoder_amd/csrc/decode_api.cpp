@@ -323,6 +323,16 @@ int jpeggpu_write_pnm(const char *path, const jpeggpu_frame_desc_t *desc, const 
    return rc;
 }
 
+int jpeggpu_write_pnm_rows(const char *path, const jpeggpu_frame_desc_t *desc, const uint8_t *raster, size_t stride, size_t rows) {
+   if (!path || !desc || !raster) { jpeggpu_internal_set_error("NULL argument"); return JPEGGPU_ERR_INVALID_ARG; }
+   if (desc->nbcomp != 1 && desc->nbcomp != 3) { jpeggpu_internal_set_error("Il faut une ou trois composante"); return JPEGGPU_ERR_NB_COMP; }
+   if (rows > jpeggpu_raster_rows(desc)) { jpeggpu_internal_set_error("plus de lignes que le raster n'en contient"); return JPEGGPU_ERR_INVALID_ARG; }
+   if (stride == 0) stride = jpeggpu_raster_row_bytes(desc);
+   int rc = write_pnm(path, desc, raster, stride, rows);
+   if (rc) jpeggpu_internal_set_error(g_derr);
+   return rc;
+}
+
 int jpeggpu_out_file_name(const char *filepath, const char *outfile, uint8_t nbcomp, uint8_t nb, char *buf, size_t cap) {
    if (!filepath || !buf) return JPEGGPU_ERR_INVALID_ARG;
    std::string n = out_name(filepath, outfile, nbcomp, nb);

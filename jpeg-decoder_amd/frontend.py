@@ -44,6 +44,7 @@ lib.jpeggpu_jpeg_decode_scan.argtypes = [_vp]
 lib.jpeggpu_jpeg_next_header.argtypes = [_vp]
 lib.jpeggpu_jpeg_render.argtypes = [_vp, _vp, _sz]
 lib.jpeggpu_write_pnm.argtypes = [C.c_char_p, C.POINTER(B.FrameDesc), _vp, _sz]
+lib.jpeggpu_write_pnm_rows.argtypes = [C.c_char_p, C.POINTER(B.FrameDesc), _vp, _sz, _sz]
 lib.jpeggpu_out_file_name.argtypes = [C.c_char_p, C.c_char_p, C.c_uint8, C.c_uint8, C.c_char_p, _sz]
 lib.jpeggpu_jpeg2ppm.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]
 
@@ -127,9 +128,14 @@ def pnm_header(desc):
     return (b"P5\n" if desc.nbcomp == 1 else b"P6\n") + b"%d %d\n255\n" % (desc.width, desc.height)
 
 
-def write_pnm(path, desc, raster):
+def write_pnm(path, desc, raster, rows=None):
+    """rows=None: every raster row like the reference; rows=desc.height: payload cropped to the header's height."""
     r = np.ascontiguousarray(raster, dtype=np.uint8)
-    B._check(lib.jpeggpu_write_pnm(str(path).encode(), C.byref(desc), r.ctypes.data, r.strides[0] if r.ndim == 2 else 0))
+    stride = r.strides[0] if r.ndim == 2 else 0
+    if rows is None:
+        B._check(lib.jpeggpu_write_pnm(str(path).encode(), C.byref(desc), r.ctypes.data, stride))
+    else:
+        B._check(lib.jpeggpu_write_pnm_rows(str(path).encode(), C.byref(desc), r.ctypes.data, stride, rows))
 
 
 def out_file_name(filepath, outfile, nbcomp, nb):

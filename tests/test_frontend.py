@@ -175,6 +175,10 @@ def test_write_pnm_keeps_padded_rows(tmp_path):
     p = tmp_path / "o.pgm"
     F.write_pnm(p, gd, raster)
     assert p.read_bytes() == b"P5\n5 3\n255\n" + raster.tobytes()   # 8 rows for a 3-row image, like the reference
+    F.write_pnm(tmp_path / "c.pgm", gd, raster, rows=3)               # optional crop to the header's height
+    assert (tmp_path / "c.pgm").read_bytes() == b"P5\n5 3\n255\n" + raster[:3].tobytes()
+    with pytest.raises(jg.JpegGpuError):
+        F.write_pnm(tmp_path / "c.pgm", gd, raster, rows=9)
     d3 = helpers.to_gpu_desc(jg, helpers.oracle_desc(2, 8, [(1, 1)] * 3))
     r3 = np.arange(8 * 6, dtype=np.uint8).reshape(8, 6)
     F.write_pnm(tmp_path / "o.ppm", d3, r3)

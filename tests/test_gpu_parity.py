@@ -206,3 +206,25 @@ def test_batch_equals_frame_by_frame(gpu):
     planes = [host[c][f * nb[c]:(f + 1) * nb[c]] for c in range(3)]
     want = orc.backend_run(d, planes, QT, mcu_rows=(10, 12))
     assert np.array_equal(got[f][160:192], want[160:192])
+
+
+def test_bench_line_contract(gpu):
+    """bench.py prints ONE JSON line with the driver's keys plus roofline and cpu_baseline (a short run)."""
+    import json
+    import subprocess
+    import sys
+    root = helpers.ROOT
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--prewarm-ms", "50", "--workload", "c5", "--frames", "4", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-800:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in res, k
+    assert res["unit"] == "MPix/s" and res["n_gpus"] == 1 and res["steps"] == 3 and res["scaling"] == "weak" and res["vs_baseline"] is None
+    assert "workload" in res["config"] and res["value"] > 0
+    rf = res["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
