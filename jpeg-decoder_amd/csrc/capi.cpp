@@ -139,6 +139,10 @@ void plan_backend(const jpeggpu_frame_desc_t *d, const jpeggpu_qtable_t *const q
    // blocks, 4:2:0 -> 32 = 192, 4:2:2 -> 64 = 256, gray -> 256), never more than the frame is wide
    uint32_t T = 1;
    while (T * 2 * per_mcu <= target_blocks) T *= 2;
+   if (const char *e = getenv("JPEGGPU_TILE_MCUS")) {   // tuning knob: any T with T*blocks_per_MCU <= 256
+      uint32_t v = (uint32_t)atoi(e);
+      if (v >= 1 && v * per_mcu <= 256) T = v;
+   }
    if (T > d->nbmcuH) T = d->nbmcuH;
    p.T = T; p.B = T * per_mcu;
    p.nbcomp = d->nbcomp; p.apply_iquant = d->apply_iquant; p.width = d->width;
