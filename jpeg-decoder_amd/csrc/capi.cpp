@@ -139,14 +139,19 @@ void plan_backend(const jpeggpu_frame_desc_t *d, const jpeggpu_qtable_t *const q
    // blocks, 4:2:0 -> 32 = 192, 4:2:2 -> 64 = 256, gray -> 256), never more than the frame is wide
    uint32_t T = 1;
    while (T * 2 * per_mcu <= target_blocks) T *= 2;
-   if (const char *e = getenv("JPEGGPU_TILE_MCUS")) {   // tuning knob: any T with T*blocks_per_MCU <= 256
+   // a frame narrower than the tile keeps a power-of-two tile (the unused lanes idle): the sub-sampling-specific
+   // kernels turn the item index into (row, quad) with a shift and a mask
+   while (T / 2 >= d->nbmcuH && T > 1) T /= 2;
+   if (const char *e = getenv("JPEGGPU_TILE_MCUS")) {   // tuning knob: any T with T*blocks_per_MCU <= 256 (not a power of two: generic kernel)
       uint32_t v = (uint32_t)atoi(e);
       if (v >= 1 && v * per_mcu <= 256) T = v;
    }
-   if (T > d->nbmcuH) T = d->nbmcuH;
    p.T = T; p.B = T * per_mcu;
    p.nbcomp = d->nbcomp; p.apply_iquant = d->apply_iquant; p.width = d->width;
    p.tile_w = T * d->max_h * 8; p.tile_rows = (uint32_t)d->max_v * 8;
+   p.wq_shift = 0xFFFFFFFFu;
+   for (uint32_t sft = 0; sft < 16; sft++)
+      if ((p.tile_w >> 2) == (1u << sft)) p.wq_shift = sft;
    uint32_t boff = 0, poff = 0;
    for (int c = 0; c < d->nbcomp; c++) {
       const jpeggpu_component_t &k = d->comp[c];
@@ -176,6 +181,7 @@ int run_device(const jpeggpu_frame_desc_t *d, uint32_t nframes, const void *cons
    const size_t row_bytes = jpeggpu_raster_row_bytes(d), rows = jpeggpu_raster_rows(d);
    if (out_stride == 0) out_stride = row_bytes;
    if (out_stride < row_bytes) return fail(JPEGGPU_ERR_INVALID_ARG, "out_stride %zu < row bytes %zu", out_stride, row_bytes);
+   if (out_stride > ((size_t)1 << 26)) return fail(JPEGGPU_ERR_INVALID_ARG, "out_stride %zu above 2^26 (the kernel addresses a tile's rows with 32-bit offsets)", out_stride);
    if (out_frame_stride == 0) out_frame_stride = out_stride * rows;
    for (int c = 0; c < d->nbcomp; c++) {
       if (!d_coef || !d_coef[c]) return fail(JPEGGPU_ERR_INVALID_ARG, "coef[%d] is NULL", c);

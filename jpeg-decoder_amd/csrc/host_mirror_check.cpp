@@ -67,6 +67,32 @@ int main(int argc, char **argv) {
             }
          }
    printf("host mirror ycc2rgb: 2^24 inputs, %zu differing\n", cbad);
+   // the packed 16-bit form (rgb_quad_pk): every (cb, cr) under pixels 0,1 with a second pair under pixels 2,3,
+   // every luma value, both chroma layouts
+   size_t pbad = 0, pn = 0;
+   for (int cb = 0; cb < 256; cb++)
+      for (int cr = 0; cr < 256; cr++) {
+         const int cb2 = (cb * 7 + 3) & 255, cr2 = (cr * 13 + 5) & 255;
+         if ((cb == 28 && cr == 228) || (cb2 == 28 && cr2 == 228)) continue;
+         const uint32_t cbw1 = (uint32_t)cb | ((uint32_t)cb << 8) | ((uint32_t)cb2 << 16) | ((uint32_t)cb2 << 24);
+         const uint32_t crw1 = (uint32_t)cr | ((uint32_t)cr << 8) | ((uint32_t)cr2 << 16) | ((uint32_t)cr2 << 24);
+         const uint32_t cbw2 = (uint32_t)cb | ((uint32_t)cb2 << 8), crw2 = (uint32_t)cr | ((uint32_t)cr2 << 8);
+         const ChromaPairs o1 = chroma_pairs<1>(cbw1 ^ 0x80808080u, crw1 ^ 0x80808080u);
+         const ChromaPairs o2 = chroma_pairs<2>(cbw2 ^ 0x80808080u, crw2 ^ 0x80808080u);
+         for (int q = 0; q < 64; q++) {
+            const uint32_t yw = (uint32_t)(4 * q) | ((uint32_t)(4 * q + 1) << 8) | ((uint32_t)(4 * q + 2) << 16) | ((uint32_t)(4 * q + 3) << 24);
+            uint8_t want[12];
+            for (int i = 0; i < 4; i++)
+               oracle_ycc2rgb_pixel((uint8_t)(4 * q + i), (uint8_t)(i < 2 ? cb : cb2), (uint8_t)(i < 2 ? cr : cr2), want + 3 * i);
+            uint32_t w1[3], w2[3];
+            rgb_quad_pk(yw, o1, w1);
+            rgb_quad_pk(yw, o2, w2);
+            pbad += (memcmp(w1, want, 12) != 0) + (memcmp(w2, want, 12) != 0);
+            pn += 2;
+         }
+      }
+   printf("host mirror packed colour path: %zu quads, %zu differing\n", pn, pbad);
+   bad += pbad;
    bad += cbad;
    printf(bad ? "host_mirror_check: FAILED\n" : "host_mirror_check: OK\n");
    return bad != 0;

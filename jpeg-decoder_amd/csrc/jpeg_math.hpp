@@ -377,4 +377,89 @@ JM_HD bool has_special_pair(uint32_t cbw, uint32_t crw) {
    return ((t - 0x01010101u) & ~t & 0x80808080u) != 0;
 }
 
+// ---- packed 16-bit form of the fast colour path (device only) --------------------------------
+// Four pixels of one raster row at a time.  The chroma offsets are the upper bits of the same 24-bit
+// products as chroma_off3, gathered two to a register as int16 pairs (pixel 0 with pixel 2, pixel 1
+// with pixel 3) by v_perm_b32; luma is widened to the same pairing; one v_pk_add_u16 adds a pair, one
+// v_sat_pk_u8_i16 clamps it to [0,255] and narrows it to two bytes (the same clamp as clamp8, since
+// |y + offset| < 2^15), and three v_perm_b32 interleave the result into r g b r | g b r g | b r g b.
+typedef short jm_s2 __attribute__((ext_vector_type(2)));
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint32_t jm_perm(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
+__device__ __forceinline__ uint32_t jm_pk_add16(uint32_t a, uint32_t b) {
+   return __builtin_bit_cast(uint32_t, (jm_us2)(__builtin_bit_cast(jm_us2, a) + __builtin_bit_cast(jm_us2, b)));
+}
+__device__ __forceinline__ uint32_t jm_pk_ashr16_7(uint32_t a) {
+   return __builtin_bit_cast(uint32_t, (jm_s2)(__builtin_bit_cast(jm_s2, a) >> (jm_s2)7));
+}
+// {sat8(a.lo16), sat8(a.hi16)} in bytes 0,1 and {sat8(b.lo16), sat8(b.hi16)} in bytes 2,3
+__device__ __forceinline__ uint32_t jm_sat2x2(uint32_t a, uint32_t b) {
+   uint32_t d;
+   asm("v_sat_pk_u8_i16_e32 %0, %1\n\t"
+       "v_sat_pk_u8_i16_sdwa %0, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD"
+       : "=&v"(d) : "v"(a), "v"(b));
+   return d;
+}
+__device__ __forceinline__ int jm_mul24(int a, int b) { return __mul24(a, b); }
+#else
+// host mirrors of the instructions above (v_perm_b32: selector bytes 0-3 pick from s1, 4-7 from s0, 0x0c = zero)
+JM_HD uint32_t jm_perm(uint32_t s0, uint32_t s1, uint32_t sel) {
+   const uint64_t src = ((uint64_t)s0 << 32) | s1;
+   uint32_t d = 0;
+   for (int i = 0; i < 4; i++) {
+      const uint32_t k = (sel >> (8 * i)) & 0xFF;
+      const uint32_t byte = k < 8 ? (uint32_t)((src >> (8 * k)) & 0xFF) : 0u;
+      d |= byte << (8 * i);
+   }
+   return d;
+}
+JM_HD uint32_t jm_pk_add16(uint32_t a, uint32_t b) { return ((a + b) & 0xFFFFu) | (((a >> 16) + (b >> 16)) << 16); }
+JM_HD uint32_t jm_pk_ashr16_7(uint32_t a) {
+   return ((uint32_t)((int)(short)(a & 0xFFFF) >> 7) & 0xFFFFu) | ((uint32_t)((int)(short)(a >> 16) >> 7) << 16);
+}
+JM_HD uint32_t jm_sat8(uint32_t h) { const int v = (short)h; return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+JM_HD uint32_t jm_sat2x2(uint32_t a, uint32_t b) {
+   return jm_sat8(a & 0xFFFF) | (jm_sat8(a >> 16) << 8) | (jm_sat8(b & 0xFFFF) << 16) | (jm_sat8(b >> 16) << 24);
+}
+JM_HD int jm_mul24(int a, int b) { return a * b; }
+#endif
+// Offsets of the chroma samples under four horizontally adjacent pixels, as int16 pairs.
+// HFC = 1: cbs/crs hold four samples (one per pixel); HFC = 2: two samples, each under two pixels.
+struct ChromaPairs { uint32_t r02, r13, g02, g13, b02, b13; };
+template <int HFC> JM_HD ChromaPairs chroma_pairs(uint32_t cbs, uint32_t crs) {
+   constexpr int N = 4 / HFC;
+   int pr[N], pb[N], pg[N];
+#pragma unroll
+   for (int ci = 0; ci < N; ci++) {
+      const int du = (int)(int8_t)(cbs >> (8 * ci)), dv = (int)(int8_t)(crs >> (8 * ci));
+      pr[ci] = jm_mul24(dv, 91881);                                        // offset = bits 31..16
+      pb[ci] = jm_mul24(du, 116130);
+      pg[ci] = jm_mul24(dv, -5990640) + jm_mul24(du, -2886855) + 120;      // offset = bits 31..23
+   }
+   ChromaPairs o;
+   constexpr uint32_t HI = 0x07060302u;   // { S1.hi16, S0.hi16 }
+   if constexpr (HFC == 1) {
+      o.r02 = jm_perm((uint32_t)pr[2], (uint32_t)pr[0], HI); o.r13 = jm_perm((uint32_t)pr[3], (uint32_t)pr[1], HI);
+      o.b02 = jm_perm((uint32_t)pb[2], (uint32_t)pb[0], HI); o.b13 = jm_perm((uint32_t)pb[3], (uint32_t)pb[1], HI);
+      o.g02 = jm_pk_ashr16_7(jm_perm((uint32_t)pg[2], (uint32_t)pg[0], HI));
+      o.g13 = jm_pk_ashr16_7(jm_perm((uint32_t)pg[3], (uint32_t)pg[1], HI));
+   } else {
+      o.r02 = o.r13 = jm_perm((uint32_t)pr[1], (uint32_t)pr[0], HI);
+      o.b02 = o.b13 = jm_perm((uint32_t)pb[1], (uint32_t)pb[0], HI);
+      o.g02 = o.g13 = jm_pk_ashr16_7(jm_perm((uint32_t)pg[1], (uint32_t)pg[0], HI));
+   }
+   return o;
+}
+// yw = four luma bytes -> the 12 output bytes
+JM_HD void rgb_quad_pk(uint32_t yw, const ChromaPairs &o, uint32_t (&w)[3]) {
+   const uint32_t y02 = yw & 0x00FF00FFu;
+   const uint32_t y13 = jm_perm(0u, yw, 0x0c030c01u);
+   const uint32_t rg = jm_sat2x2(jm_pk_add16(y02, o.r02), jm_pk_add16(y02, o.g02));   // r0 r2 g0 g2
+   const uint32_t br = jm_sat2x2(jm_pk_add16(y02, o.b02), jm_pk_add16(y13, o.r13));   // b0 b2 r1 r3
+   const uint32_t gb = jm_sat2x2(jm_pk_add16(y13, o.g13), jm_pk_add16(y13, o.b13));   // g1 g3 b1 b3
+   w[0] = jm_perm(br, rg, 0x06040200u);   // r0 g0 b0 r1
+   w[1] = jm_perm(rg, gb, 0x07050200u);   // g1 b1 r2 g2
+   w[2] = jm_perm(gb, br, 0x07050301u);   // b2 r3 g3 b3
+}
+
 }  // namespace jpegmath

@@ -27,6 +27,16 @@
 #define JM_WAVES_PER_EU 6
 #endif
 
+// Raster rows start wherever out_stride puts them (a packed RGB row of odd width is not 4-byte aligned).  gfx950
+// under HSA runs with unaligned dword access enabled, so the 12-byte store is issued at any address.
+#if defined(JM_STORE_ALIGNED_ONLY)
+#define JM_ALIGN_TEST(dst) && ((uintptr_t)(dst) & 3) == 0
+#define JM_STORE_ALIGN 4
+#else
+#define JM_ALIGN_TEST(dst)
+#define JM_STORE_ALIGN 1
+#endif
+
 namespace jpeggpu_k {
 
 using namespace jpegmath;
@@ -62,10 +72,10 @@ __device__ __forceinline__ void store_rgb_quad(uint8_t *dst, uint32_t w0, uint32
 #if defined(JM_DIAG_NOSTORE)
    if ((w0 ^ w1 ^ w2) != 0x12345678u) return;
 #endif
-   if (n == 4 && ((uintptr_t)dst & 3) == 0) {
+   if (n == 4 JM_ALIGN_TEST(dst)) {
 #if JM_NT_STORE
       typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-      __builtin_nontemporal_store(u32x3{w0, w1, w2}, reinterpret_cast<u32x3 __attribute__((aligned(4))) *>(dst));
+      __builtin_nontemporal_store(u32x3{w0, w1, w2}, reinterpret_cast<u32x3 __attribute__((aligned(JM_STORE_ALIGN))) *>(dst));
 #else
       rgb4_t v = { w0, w1, w2 };
       *reinterpret_cast<rgb4_t *>(dst) = v;
@@ -113,26 +123,32 @@ __device__ __forceinline__ void pixel_phase(const BackendParams &p, const uint8_
    if constexpr (HFC != 0) {
       // Y at full resolution, Cb and Cr share (HFC, VFC).  One item = 4 pixels wide x VFC rows, so
       // every chroma sample's offsets are computed once for all the pixels that replicate it.
-      const uint32_t nit = wq * (p.tile_rows / VFC);
+      // tile_w / 4 is a power of two here (pick_kernel), and the planes are dense in LDS (pitch0 = tile_w,
+      // pitch1 = pitch2 = tile_w / HFC): item -> (row, quad) is a shift and a mask, and the item index itself
+      // is the word offset of the item's chroma samples
+      const uint32_t ws = p.wq_shift;
+      const uint32_t nit = (p.tile_rows / VFC) << ws;
+      const uint32_t rem = p.width - x0;                       // pixels of this tile inside the frame
+      uint8_t *tile_out = out + (size_t)x0 * 3;                // uniform; rows are reached with 32-bit offsets
+      const uint32_t stride = (uint32_t)p.out_stride;          // <= 2^26 (run_device)
       for (uint32_t it = tid; it < nit; it += nt) {
-         const uint32_t yi = iy, x = ix * 4;
-         iy += dy; ix += dx;
-         if (ix >= wq) { ix -= wq; iy++; }
-         if (x0 + x >= p.width) continue;
-         const uint32_t n = min(4u, p.width - (x0 + x));
+         const uint32_t yi = it >> ws, x = (it & (wq - 1)) * 4;
+         if (x >= rem) continue;
+         const uint32_t n = min(4u, rem - x);
          const uint32_t y = yi * VFC;
          uint32_t cbw, crw;
          if (HFC == 1) {
-            cbw = *reinterpret_cast<const uint32_t *>(pl1 + yi * pitch1 + x);
-            crw = *reinterpret_cast<const uint32_t *>(pl2 + yi * pitch2 + x);
+            cbw = *reinterpret_cast<const uint32_t *>(pl1 + it * 4);
+            crw = *reinterpret_cast<const uint32_t *>(pl2 + it * 4);
          } else {
-            cbw = *reinterpret_cast<const uint16_t *>(pl1 + yi * pitch1 + (x >> 1));
-            crw = *reinterpret_cast<const uint16_t *>(pl2 + yi * pitch2 + (x >> 1));
+            cbw = *reinterpret_cast<const uint16_t *>(pl1 + it * 2);
+            crw = *reinterpret_cast<const uint16_t *>(pl2 + it * 2);
             cbw |= 0x01010000u;   // unused byte lanes can never look like the special pair
          }
+         const uint8_t *yrow = pl0 + (it + yi * ((VFC - 1) << ws)) * 4;
          uint32_t yy[VFC];
 #pragma unroll
-         for (int v = 0; v < VFC; v++) yy[v] = *reinterpret_cast<const uint32_t *>(pl0 + (y + v) * pitch0 + x);
+         for (int v = 0; v < VFC; v++) yy[v] = *reinterpret_cast<const uint32_t *>(yrow + v * pitch0);
          uint32_t w[VFC][3];
 #if defined(JM_DIAG_NOCOLOR)
          if (true) {
@@ -153,6 +169,7 @@ __device__ __forceinline__ void pixel_phase(const BackendParams &p, const uint8_
                w[v][0] = px[0] | (px[1] << 24); w[v][1] = (px[1] >> 8) | (px[2] << 16); w[v][2] = (px[2] >> 16) | (px[3] << 8);
             }
          } else {
+#if defined(JM_COLOR_SCALAR)
             Off3 o[4 / HFC];
             const uint32_t cbs = cbw ^ 0x80808080u, crs = crw ^ 0x80808080u;   // bytes become cb-128, cr-128 (int8)
 #pragma unroll
@@ -170,10 +187,15 @@ __device__ __forceinline__ void pixel_phase(const BackendParams &p, const uint8_
                w[v][1] = g[1] | (b[1] << 8) | (r[2] << 16) | (g[2] << 24);
                w[v][2] = b[2] | (r[3] << 8) | (g[3] << 16) | (b[3] << 24);
             }
+#else
+            const ChromaPairs o = chroma_pairs<HFC>(cbw ^ 0x80808080u, crw ^ 0x80808080u);   // bytes become cb-128, cr-128 (int8)
+#pragma unroll
+            for (int v = 0; v < VFC; v++) rgb_quad_pk(yy[v], o, w[v]);
+#endif
          }
 #pragma unroll
          for (int v = 0; v < VFC; v++)
-            store_rgb_quad(out + (size_t)(y + v) * p.out_stride + (size_t)(x0 + x) * 3, w[v][0], w[v][1], w[v][2], n);
+            store_rgb_quad(tile_out + ((y + v) * stride + x * 3), w[v][0], w[v][1], w[v][2], n);
       }
    } else {
       // generic replicate upsampling, any integer factors (src/decoder_utils.c:72-80)
@@ -279,8 +301,11 @@ __device__ __forceinline__ void transform_block_slow(const BackendParams &p, con
 }
 
 __device__ __forceinline__ const uint8_t *record_ptr(const BlockCtx &k, uint32_t tile, uint32_t m, uint32_t frame, bool &in_plane) {
-   const uint32_t col = tile * k.bw + k.bxl;
+   uint32_t col = tile * k.bw + k.bxl;
    in_plane = col < k.nbH;
+#if !defined(JM_LOAD_ZEROFILL)
+   col = min(col, k.nbH - 1);   // lanes right of the plane read its last column: their samples are never stored
+#endif
    return k.coef + (size_t)frame * k.frame_stride + (((size_t)m * k.vs + k.by) * k.nbH + col) * 128;
 }
 
@@ -307,7 +332,12 @@ __device__ __forceinline__ void backend_body(const BackendParams &p) {
 #if defined(JM_DIAG_NOLOAD)
       in_plane = false;
 #endif
+#if !defined(JM_LOAD_ZEROFILL) && !defined(JM_DIAG_NOLOAD)
+      (void)in_plane;
+      if (true) {   // idle lanes decode as block 0 and lanes right of the plane are clamped: every address is valid
+#else
       if (active && in_plane) {
+#endif
 #pragma unroll
          for (int i = 0; i < 8; i++) v[i] = src[i];   // NOT non-temporal: a lane's 8 loads share one line (nt: 1.6x slower)
       } else {
@@ -360,7 +390,7 @@ typedef void (*BackendFn)(const BackendParams);
 static BackendFn pick_kernel(const BackendParams &p) {
    if (p.slow_coef) return (BackendFn)backend_kernel_slow;
 #define JM_PICK(H, V) ((BackendFn)backend_kernel<H, V>)
-   if (p.nbcomp == 3 && p.hf[0] == 1 && p.vf[0] == 1 && p.hf[1] == p.hf[2] && p.vf[1] == p.vf[2]) {
+   if (p.nbcomp == 3 && p.wq_shift != 0xFFFFFFFFu && p.hf[0] == 1 && p.vf[0] == 1 && p.hf[1] == p.hf[2] && p.vf[1] == p.vf[2]) {
       const uint32_t h = p.hf[1], v = p.vf[1];
       if (h == 1 && v == 1) return JM_PICK(1, 1);
       if (h == 2 && v == 1) return JM_PICK(2, 1);
@@ -438,11 +468,27 @@ __global__ void __launch_bounds__(64) idct_slow_kernel(const int16_t *in, uint8_
    for (uint32_t xy = 0; xy < 64; xy++) dst[xy] = (uint8_t)slow_sample(m, coef + xy * 64);   // data[x][y]
 }
 
+// Four pixels per thread through the SAME arithmetic as the fused kernel's pixel phase (packed fast path,
+// exact per-pixel form for a wave that holds the special chroma pair), so that the exhaustive 2^24 test of
+// this stage also covers the fused path's colour code.
 __global__ void ycc2rgb_kernel(const uint8_t *y, const uint8_t *cb, const uint8_t *cr, uint8_t *rgb, size_t n) {
-   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-   if (i >= n) return;
-   uint32_t v = ycc_to_rgb(y[i], chroma_offsets(cb[i], cr[i]));
-   rgb[3 * i] = (uint8_t)v; rgb[3 * i + 1] = (uint8_t)(v >> 8); rgb[3 * i + 2] = (uint8_t)(v >> 16);
+   const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+   if (i0 >= n) return;
+   const uint32_t cnt = (uint32_t)(n - i0 < 4 ? n - i0 : 4);
+   uint32_t yw = 0, cbw = 0, crw = 0;
+   for (uint32_t j = 0; j < cnt; j++) {
+      yw |= (uint32_t)y[i0 + j] << (8 * j); cbw |= (uint32_t)cb[i0 + j] << (8 * j); crw |= (uint32_t)cr[i0 + j] << (8 * j);
+   }
+   uint32_t w[3];
+   if (__any(has_special_pair(cbw, crw))) {
+      uint32_t px[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) px[i] = ycc_to_rgb((yw >> (8 * i)) & 0xFF, chroma_offsets((cbw >> (8 * i)) & 0xFF, (crw >> (8 * i)) & 0xFF));
+      w[0] = px[0] | (px[1] << 24); w[1] = (px[1] >> 8) | (px[2] << 16); w[2] = (px[2] >> 16) | (px[3] << 8);
+   } else {
+      rgb_quad_pk(yw, chroma_pairs<1>(cbw ^ 0x80808080u, crw ^ 0x80808080u), w);
+   }
+   for (uint32_t j = 0; j < 3 * cnt; j++) rgb[3 * i0 + j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
 }
 
 static inline unsigned nblocks(size_t work, unsigned per) { return (unsigned)((work + per - 1) / per); }
@@ -470,7 +516,7 @@ hipError_t launch_idct_slow(const void *d_in, void *d_out, size_t n, const float
 }
 hipError_t launch_ycc2rgb(const uint8_t *d_y, const uint8_t *d_cb, const uint8_t *d_cr, uint8_t *d_rgb, size_t n, hipStream_t s) {
    if (n == 0) return hipSuccess;
-   hipLaunchKernelGGL(ycc2rgb_kernel, dim3(nblocks(n, 256)), dim3(256), 0, s, d_y, d_cb, d_cr, d_rgb, n);
+   hipLaunchKernelGGL(ycc2rgb_kernel, dim3(nblocks((n + 3) / 4, 256)), dim3(256), 0, s, d_y, d_cb, d_cr, d_rgb, n);
    return hipGetLastError();
 }
 
