@@ -161,6 +161,10 @@ void plan_backend(const jpeggpu_frame_desc_t *d, const jpeggpu_qtable_t *const q
       boff += T * k.hs * k.vs; poff += T * k.hs * k.vs * 64;
    }
    for (int c = d->nbcomp; c < 4; c++) p.boff[c] = boff;
+   p.wave_uniform = 1;
+   for (int c = 1; c <= d->nbcomp; c++)
+      if (p.boff[c] % 64) p.wave_uniform = 0;
+   if (getenv("JPEGGPU_NO_UNIFORM")) p.wave_uniform = 0;   // diagnostic: per-lane prologue everywhere
    if (d->apply_iquant)
       for (int i = 0; i < 4; i++)
          if (qt[i]) pack_qtable(qt[i], p.qt[i]);

@@ -107,11 +107,12 @@ JM_HD uint32_t to_u8(float s) {
 // instruction saturates to [0,255] and follows MODE.fp_round, so it is issued with the fp32
 // rounding mode switched to round-toward-zero (probed on gfx950 by tools/probe_round.hip).  The
 // whole mode window is a single asm statement, so no other fp32 instruction can be scheduled into it.
-JM_HD uint2 pack_row(const float (&u)[8]) {
+// x[] already carries the +128
+JM_HD uint32_t to_u8_biased(float x) { return (uint32_t)(int)__builtin_fminf(__builtin_fmaxf(x, 0.0f), 255.0f); }
+JM_HD uint2 pack_row_biased(const float (&x)[8]) {
    uint2 w;
 #if defined(__HIP_DEVICE_COMPILE__)
-   float x0 = u[0] + 128.0f, x1 = u[1] + 128.0f, x2 = u[2] + 128.0f, x3 = u[3] + 128.0f;
-   float x4 = u[4] + 128.0f, x5 = u[5] + 128.0f, x6 = u[6] + 128.0f, x7 = u[7] + 128.0f;
+   const float x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3], x4 = x[4], x5 = x[5], x6 = x[6], x7 = x[7];
    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
                 "s_nop 1\n\t"
                 "v_cvt_pk_u8_f32 %0, %2, 0, 0\n\t"
@@ -127,10 +128,16 @@ JM_HD uint2 pack_row(const float (&u)[8]) {
                 : "=&v"(w.x), "=&v"(w.y)
                 : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(x6), "v"(x7));
 #else
-   w.x = to_u8(u[0]) | (to_u8(u[1]) << 8) | (to_u8(u[2]) << 16) | (to_u8(u[3]) << 24);
-   w.y = to_u8(u[4]) | (to_u8(u[5]) << 8) | (to_u8(u[6]) << 16) | (to_u8(u[7]) << 24);
+   w.x = to_u8_biased(x[0]) | (to_u8_biased(x[1]) << 8) | (to_u8_biased(x[2]) << 16) | (to_u8_biased(x[3]) << 24);
+   w.y = to_u8_biased(x[4]) | (to_u8_biased(x[5]) << 8) | (to_u8_biased(x[6]) << 16) | (to_u8_biased(x[7]) << 24);
 #endif
    return w;
+}
+JM_HD uint2 pack_row(const float (&u)[8]) {
+   float x[8];
+#pragma unroll
+   for (int i = 0; i < 8; i++) x[i] = u[i] + 128.0f;
+   return pack_row_biased(x);
 }
 
 // 2-D transform of one block held as m[c][r] (column c, row r), idct_opt (src/idct_opt.c:93-117):
@@ -258,6 +265,28 @@ JM_HD void idct8_row_pk(f32x2 P0, f32x2 P1, f32x2 P2, f32x2 P3, float (&o)[8]) {
    o[0] = O01.x; o[1] = O01.y; o[2] = O32.y; o[3] = O32.x; o[4] = O45.x; o[5] = O45.y; o[6] = O76.y; o[7] = O76.x;
 }
 
+// Same row with the level shift (+128, src/idct_opt.c:110) applied to the pairs: four packed adds instead of
+// eight scalar ones, the same IEEE addition per element.
+JM_HD void idct8_row_pk_biased(f32x2 P0, f32x2 P1, f32x2 P2, f32x2 P3, float (&o)[8]) {
+   const f32x2 Q2 = jm_sumdiff(P2);
+   const f32x2 Q3 = mul_hl(P3, JM_RH2, JM_RL2);
+   const f32x2 S01 = jm_sumdiff(P0);
+   const f32x2 XY = mul_hl(P1, JM_KH2, JM_KL2);
+   const f32x2 S23 = jm_sub_add(XY * (f32x2)JM_C6, jm_swap_mul(XY, JM_S6));
+   const f32x2 A = jm_cross_a(Q2, Q3);
+   const f32x2 B = jm_add_sub(Q2, Q3);
+   const f32x2 U = jm_add_swap(S01, S23);
+   const f32x2 V = jm_sub_swap(S01, S23);
+   const f32x2 Cc = f32x2{JM_C3, JM_C1}, Sc = f32x2{JM_S3, JM_S1};
+   const f32x2 W45 = A * Cc - B * Sc;
+   const f32x2 W76 = B * Cc + A * Sc;
+   const f32x2 O01 = mul_hl(U + W76, JM_SH8, JM_SL8) + (f32x2)128.0f;
+   const f32x2 O76 = mul_hl(U - W76, JM_SH8, JM_SL8) + (f32x2)128.0f;
+   const f32x2 O32 = mul_hl(V + W45, JM_SH8, JM_SL8) + (f32x2)128.0f;
+   const f32x2 O45 = mul_hl(V - W45, JM_SH8, JM_SL8) + (f32x2)128.0f;
+   o[0] = O01.x; o[1] = O01.y; o[2] = O32.y; o[3] = O32.x; o[4] = O45.x; o[5] = O45.y; o[6] = O76.y; o[7] = O76.x;
+}
+
 // Column -> (pair, half) of the pass-1 pairing (0,4) (2,6) (1,7) (3,5).
 #define JM_RP_PAIR { 0, 2, 1, 3, 0, 3, 1, 2 }
 #define JM_RP_HALF { 0, 0, 0, 0, 1, 1, 1, 1 }
@@ -267,8 +296,8 @@ JM_HD void idct_block_rp(f32x2 (&p1)[4][8], uint2 (&row)[8]) {
 #pragma unroll
    for (int r = 0; r < 8; r++) {
       float u[8];
-      idct8_row_pk(p1[0][r], p1[1][r], p1[2][r], p1[3][r], u);
-      row[r] = pack_row(u);
+      idct8_row_pk_biased(p1[0][r], p1[1][r], p1[2][r], p1[3][r], u);
+      row[r] = pack_row_biased(u);
    }
 }
 
@@ -297,6 +326,33 @@ JM_HD void dequant_izz(const uint32_t (&zw)[32], const uint32_t (&qw)[32], float
       jm_us2 pr = a * b;
       m[ZC[2 * i]][ZR[2 * i]] = (float)(int)(short)pr.x;
       m[ZC[2 * i + 1]][ZR[2 * i + 1]] = (float)(int)(short)pr.y;
+   }
+}
+
+// iquant alone on the packed words (v_pk_mul_lo_u16), and the inverse zigzag + int16 -> float of already
+// dequantised words into the pairing of idct_block_rp / into m[col][row].
+JM_HD uint32_t iquant_word(uint32_t zw, uint32_t qw) {
+   return __builtin_bit_cast(uint32_t, (jm_us2)(__builtin_bit_cast(jm_us2, zw) * __builtin_bit_cast(jm_us2, qw)));
+}
+JM_HD void izz_rp(const uint32_t (&zw)[32], f32x2 (&p1)[4][8]) {
+   constexpr uint8_t ZR[64] = JM_ZZ_ROWS;
+   constexpr uint8_t ZC[64] = JM_ZZ_COLS;
+   constexpr uint8_t PP[8] = JM_RP_PAIR;
+   constexpr uint8_t PH[8] = JM_RP_HALF;
+#pragma unroll
+   for (int i = 0; i < 32; i++) {
+      const float f0 = (float)(int)(short)(zw[i] & 0xFFFF), f1 = (float)(int)(short)(zw[i] >> 16);
+      if (PH[ZC[2 * i]]) p1[PP[ZC[2 * i]]][ZR[2 * i]].y = f0; else p1[PP[ZC[2 * i]]][ZR[2 * i]].x = f0;
+      if (PH[ZC[2 * i + 1]]) p1[PP[ZC[2 * i + 1]]][ZR[2 * i + 1]].y = f1; else p1[PP[ZC[2 * i + 1]]][ZR[2 * i + 1]].x = f1;
+   }
+}
+JM_HD void izz_plain(const uint32_t (&zw)[32], float (&m)[8][8]) {
+   constexpr uint8_t ZR[64] = JM_ZZ_ROWS;
+   constexpr uint8_t ZC[64] = JM_ZZ_COLS;
+#pragma unroll
+   for (int i = 0; i < 32; i++) {
+      m[ZC[2 * i]][ZR[2 * i]] = (float)(int)(short)(zw[i] & 0xFFFF);
+      m[ZC[2 * i + 1]][ZR[2 * i + 1]] = (float)(int)(short)(zw[i] >> 16);
    }
 }
 

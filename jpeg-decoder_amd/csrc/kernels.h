@@ -23,6 +23,7 @@ struct BackendParams {
    uint32_t B;                     // blocks per tile = T * sum(hs*vs)
    uint32_t tile_w;                // pixels per tile row  = T * max_h * 8
    uint32_t tile_rows;             // raster rows per tile = max_v * 8
+   uint32_t wave_uniform;          // 1: every boff[] is a multiple of 64 -> each wave holds blocks of one component
    uint32_t wq_shift;              // log2(tile_w / 4) when tile_w / 4 is a power of two, else 0xFFFFFFFF (generic kernel only)
    uint32_t nbH[3];                // blocks per plane row (nbmcuH*hs)
    uint32_t vs[3];                 // block rows per MCU row

@@ -222,27 +222,13 @@ __device__ __forceinline__ void pixel_phase(const BackendParams &p, const uint8_
    }
 }
 
-// Phase 1 of one block: dequantise + both IDCT passes in registers, 8 rows of 8 samples to the
-// component's u8 plane in LDS.  v = the block's 128-byte blocl16_t record.
-__device__ __forceinline__ void transform_block(const BackendParams &p, const BlockCtx &k, const uint4 (&v)[8], const uint32_t *qt_lds,
-                                                uint8_t *lds) {
+// Phase 1 of one block: both IDCT passes in registers, 8 rows of 8 samples to the component's u8 plane in
+// LDS.  zw = the block's 64 coefficients after iquant, zigzag order, two int16 per word.
+__device__ __forceinline__ void transform_block(const uint32_t (&zw)[32], uint8_t *plane, uint32_t pitch) {
    uint2 rows[8];
    {
       f32x2 mtx[4][8];
-      const uint4 *q4 = reinterpret_cast<const uint4 *>(qt_lds + k.idq * 32);
-      uint32_t zw[32], qw[32];
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-         uint4 q = make_uint4(0x00010001u, 0x00010001u, 0x00010001u, 0x00010001u);
-         if (p.apply_iquant) q = q4[i];
-         zw[4 * i] = v[i].x; zw[4 * i + 1] = v[i].y; zw[4 * i + 2] = v[i].z; zw[4 * i + 3] = v[i].w;
-         qw[4 * i] = q.x; qw[4 * i + 1] = q.y; qw[4 * i + 2] = q.z; qw[4 * i + 3] = q.w;
-      }
-#if defined(JM_IDCT_HY)
-      dequant_izz_pk(zw, qw, mtx);
-#else
-      dequant_izz_rp(zw, qw, mtx);   // pass-1 pairing (0,4)(2,6)(1,7)(3,5): pass 2 stays packed within a row
-#endif
+      izz_rp(zw, mtx);   // pass-1 pairing (0,4)(2,6)(1,7)(3,5): pass 2 stays packed within a row
 #if defined(JM_DIAG_NOIDCT)
 #pragma unroll
       for (int r = 0; r < 8; r++) { float u[8];
@@ -250,15 +236,9 @@ __device__ __forceinline__ void transform_block(const BackendParams &p, const Bl
          for (int c2 = 0; c2 < 8; c2++) u[c2] = (c2 & 1) ? mtx[c2 >> 1][r].y : mtx[c2 >> 1][r].x;
          rows[r] = pack_row(u); }
 #else
-#if defined(JM_IDCT_HY)
-      idct_block_hy(mtx, rows);
-#else
       idct_block_rp(mtx, rows);
 #endif
-#endif
    }
-   const uint32_t pitch = k.bw * 8;
-   uint8_t *plane = lds + k.plane_off + (k.by * 8) * pitch + k.bxl * 8;
 #pragma unroll
    for (int r = 0; r < 8; r++) *reinterpret_cast<uint2 *>(plane + r * pitch) = rows[r];
 }
@@ -280,24 +260,12 @@ __device__ __forceinline__ uint32_t slow_sample(const float (&m)[8][8], const fl
    return to_u8(sum);
 }
 
-__device__ __forceinline__ void transform_block_slow(const BackendParams &p, const BlockCtx &k, const uint4 (&v)[8], const uint32_t *qt_lds,
-                                                  uint8_t *lds) {
+__device__ __forceinline__ void transform_block_slow(const uint32_t (&zw)[32], uint8_t *plane, uint32_t pitch, const float *__restrict__ coef) {
    float m[8][8];
-   const uint4 *q4 = reinterpret_cast<const uint4 *>(qt_lds + k.idq * 32);
-   uint32_t zw[32], qw[32];
-#pragma unroll
-   for (int i = 0; i < 8; i++) {
-      uint4 q = make_uint4(0x00010001u, 0x00010001u, 0x00010001u, 0x00010001u);
-      if (p.apply_iquant) q = q4[i];
-      zw[4 * i] = v[i].x; zw[4 * i + 1] = v[i].y; zw[4 * i + 2] = v[i].z; zw[4 * i + 3] = v[i].w;
-      qw[4 * i] = q.x; qw[4 * i + 1] = q.y; qw[4 * i + 2] = q.z; qw[4 * i + 3] = q.w;
-   }
-   dequant_izz(zw, qw, m);   // m[lambda][mu] = bloct16_t.data[lambda][mu] (src/iqzz.c:23)
-   const uint32_t pitch = k.bw * 8;
-   uint8_t *plane = lds + k.plane_off + (k.by * 8) * pitch + k.bxl * 8;
+   izz_plain(zw, m);   // m[lambda][mu] = bloct16_t.data[lambda][mu] (src/iqzz.c:23)
 #pragma unroll 1
    for (uint32_t xy = 0; xy < 64; xy++)   // res->data[x][y]: column x, row y
-      plane[(xy & 7) * pitch + (xy >> 3)] = (uint8_t)slow_sample(m, p.slow_coef + xy * 64);
+      plane[(xy & 7) * pitch + (xy >> 3)] = (uint8_t)slow_sample(m, coef + xy * 64);
 }
 
 __device__ __forceinline__ const uint8_t *record_ptr(const BlockCtx &k, uint32_t tile, uint32_t m, uint32_t frame, bool &in_plane) {
@@ -313,6 +281,12 @@ __device__ __forceinline__ const uint8_t *record_ptr(const BlockCtx &k, uint32_t
 // One workgroup = one tile of T MCUs of one MCU row, one thread per 8x8 block.  Each lane pulls its
 // own 128-byte record with 8 x 16-byte loads (one full cache line per lane; tools/ubench_read.hip:
 // 6.4-6.7 TB/s, no slower than lane-coalesced loads and no LDS staging or extra barrier needed).
+//
+// Two prologues.  When every wave of the tile holds blocks of ONE component (p.wave_uniform: all component
+// boundaries are multiples of 64, e.g. 4:4:4 and 4:2:2 with 64 MCUs per tile) the component, its plane
+// geometry and its quantisation table are wave-uniform: they live in SGPRs, the table is 32 scalar loads from
+// the kernel arguments, and nothing is staged in LDS.  Otherwise (4:2:0: Cb and Cr share a wave) every lane
+// selects its component's fields with v_cndmask and the tables go through LDS.
 template <int HFC, int VFC, bool SLOW>   // chroma factors; 0 = generic path (any factors, any component)
 __device__ __forceinline__ void backend_body(const BackendParams &p) {
    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -322,39 +296,98 @@ __device__ __forceinline__ void backend_body(const BackendParams &p) {
    const long long ts0 = __builtin_amdgcn_s_memtime();
    const long long tr0 = __builtin_amdgcn_s_memrealtime();
 #endif
-   uint32_t *qt_lds = reinterpret_cast<uint32_t *>(lds + (size_t)nt * 64);
-   const bool active = tid < p.B;
-   const BlockCtx k = decode_block(p, active ? tid : 0);
-   uint4 v[8];
-   {
-      bool in_plane;
-      const uint4 *src = reinterpret_cast<const uint4 *>(record_ptr(k, tile, m, frame, in_plane));
-#if defined(JM_DIAG_NOLOAD)
-      in_plane = false;
+   uint32_t zw[32];        // the block's record, dequantised in place
+   uint8_t *plane;         // first sample of the block in its component's LDS plane
+   uint32_t pitch;         // bytes per row of that plane
+   bool active;
+#if defined(JM_DIAG_STAMP)
+   long long ts1;
 #endif
-#if !defined(JM_LOAD_ZEROFILL) && !defined(JM_DIAG_NOLOAD)
-      (void)in_plane;
-      if (true) {   // idle lanes decode as block 0 and lanes right of the plane are clamped: every address is valid
-#else
-      if (active && in_plane) {
-#endif
+#if !defined(JM_NO_UNIFORM_PATH)
+   if (p.wave_uniform) {
+      const uint32_t wb = __builtin_amdgcn_readfirstlane(tid);   // first block of this wave
+      const uint32_t c = (p.nbcomp == 3) ? (uint32_t)(wb >= p.boff[1]) + (uint32_t)(wb >= p.boff[2]) : 0u;
+      const uint32_t bw = p.bw[c], nbH = p.nbH[c], vs = p.vs[c];
+      const uint32_t r = tid - p.boff[c];
+      uint32_t by = 0;
+      if (vs > 1) by = (uint32_t)(r >= bw) + (uint32_t)(r >= 2 * bw) + (uint32_t)(r >= 3 * bw);
+      const uint32_t bxl = r - by * bw;
+      const uint32_t col = min(tile * bw + bxl, nbH - 1);   // lanes right of the plane read its last column: never stored
+      const uint8_t *base = static_cast<const uint8_t *>(p.coef[c]) + (size_t)frame * p.coef_frame_stride[c] +
+                            (size_t)m * vs * nbH * 128;      // uniform; one MCU row of a plane is < 2^32 bytes
+      const uint4 *src = reinterpret_cast<const uint4 *>(base + (by * nbH + col) * 128u);
+      uint4 v[8];
 #pragma unroll
-         for (int i = 0; i < 8; i++) v[i] = src[i];   // NOT non-temporal: a lane's 8 loads share one line (nt: 1.6x slower)
+      for (int i = 0; i < 8; i++) v[i] = src[i];   // NOT non-temporal: a lane's 8 loads share one line (nt: 1.6x slower)
+#if defined(JM_DIAG_STAMP)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ts1 = __builtin_amdgcn_s_memtime();
+#endif
+      if (p.apply_iquant) {
+         const uint32_t *q = p.qt[p.idq[c]];
+#pragma unroll
+         for (int i = 0; i < 8; i++) {
+            zw[4 * i] = iquant_word(v[i].x, q[4 * i]); zw[4 * i + 1] = iquant_word(v[i].y, q[4 * i + 1]);
+            zw[4 * i + 2] = iquant_word(v[i].z, q[4 * i + 2]); zw[4 * i + 3] = iquant_word(v[i].w, q[4 * i + 3]);
+         }
       } else {
 #pragma unroll
-         for (int i = 0; i < 8; i++) v[i] = make_uint4(0, 0, 0, 0);
+         for (int i = 0; i < 8; i++) { zw[4 * i] = v[i].x; zw[4 * i + 1] = v[i].y; zw[4 * i + 2] = v[i].z; zw[4 * i + 3] = v[i].w; }
       }
-   }
-   if (p.apply_iquant && tid < 128) qt_lds[tid] = p.qt[tid >> 5][tid & 31];
-   if (p.apply_iquant && nt < 128) qt_lds[tid + 64] = p.qt[(tid >> 5) + 2][tid & 31];   // nt == 64
-   __syncthreads();
-#if defined(JM_DIAG_STAMP)
-   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-   const long long ts1 = __builtin_amdgcn_s_memtime();
+      pitch = bw * 8;
+      plane = lds + p.plane_off[c] + (by * 8) * pitch + bxl * 8;
+      active = true;        // B is a multiple of 64 here
+   } else
 #endif
+   {
+      uint32_t *qt_lds = reinterpret_cast<uint32_t *>(lds + (size_t)nt * 64);
+      active = tid < p.B;
+      const BlockCtx k = decode_block(p, active ? tid : 0);
+      uint4 v[8];
+      {
+         bool in_plane;
+         const uint4 *src = reinterpret_cast<const uint4 *>(record_ptr(k, tile, m, frame, in_plane));
+#if defined(JM_DIAG_NOLOAD)
+         in_plane = false;
+#endif
+#if !defined(JM_LOAD_ZEROFILL) && !defined(JM_DIAG_NOLOAD)
+         (void)in_plane;
+         if (true) {   // idle lanes decode as block 0 and lanes right of the plane are clamped: every address is valid
+#else
+         if (active && in_plane) {
+#endif
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = src[i];
+         } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = make_uint4(0, 0, 0, 0);
+         }
+      }
+      if (p.apply_iquant && tid < 128) qt_lds[tid] = p.qt[tid >> 5][tid & 31];
+      if (p.apply_iquant && nt < 128) qt_lds[tid + 64] = p.qt[(tid >> 5) + 2][tid & 31];   // nt == 64
+      __syncthreads();
+#if defined(JM_DIAG_STAMP)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ts1 = __builtin_amdgcn_s_memtime();
+#endif
+      if (p.apply_iquant) {
+         const uint4 *q4 = reinterpret_cast<const uint4 *>(qt_lds + k.idq * 32);
+#pragma unroll
+         for (int i = 0; i < 8; i++) {
+            const uint4 q = q4[i];
+            zw[4 * i] = iquant_word(v[i].x, q.x); zw[4 * i + 1] = iquant_word(v[i].y, q.y);
+            zw[4 * i + 2] = iquant_word(v[i].z, q.z); zw[4 * i + 3] = iquant_word(v[i].w, q.w);
+         }
+      } else {
+#pragma unroll
+         for (int i = 0; i < 8; i++) { zw[4 * i] = v[i].x; zw[4 * i + 1] = v[i].y; zw[4 * i + 2] = v[i].z; zw[4 * i + 3] = v[i].w; }
+      }
+      pitch = k.bw * 8;
+      plane = lds + k.plane_off + (k.by * 8) * pitch + k.bxl * 8;
+   }
    if (active) {
-      if constexpr (SLOW) transform_block_slow(p, k, v, qt_lds, lds);
-      else transform_block(p, k, v, qt_lds, lds);
+      if constexpr (SLOW) transform_block_slow(zw, plane, pitch, p.slow_coef);
+      else transform_block(zw, plane, pitch);
    }
 #if defined(JM_DIAG_STAMP)
    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
