@@ -134,17 +134,25 @@ void plan_backend(const jpeggpu_frame_desc_t *d, const jpeggpu_qtable_t *const q
    uint32_t target_blocks = 256;
    if (const char *e = getenv("JPEGGPU_TARGET_BLOCKS")) target_blocks = (uint32_t)atoi(e);   // tuning knob
    if (target_blocks < 48) target_blocks = 48;          // one MCU can hold 3 * 4*4 blocks
-   if (target_blocks > 256) target_blocks = 256;        // __launch_bounds__(256)
+   if (target_blocks > kMaxThreads) target_blocks = kMaxThreads;   // __launch_bounds__
    // T MCUs per tile: the largest power of two that fits the block budget (4:4:4 -> 64 MCUs = 192
-   // blocks, 4:2:0 -> 32 = 192, 4:2:2 -> 64 = 256, gray -> 256), never more than the frame is wide
+   // blocks, 4:2:0 -> 64 = 384 (below), 4:2:2 -> 64 = 256, gray -> 256), never wider than the frame needs
    uint32_t T = 1;
    while (T * 2 * per_mcu <= target_blocks) T *= 2;
+   // 6 blocks per MCU (4:2:0, 4:1:1): 32 MCUs would put Cb and Cr into one wave; 64 MCUs = 384 blocks keep every
+   // wave on one component (the kernel's scalar prologue) and measured 1.7% faster (profiles/r01_kernel_experiments.txt)
+   auto wave_uniform = [&](uint32_t t) {
+      uint32_t b = 0;
+      for (int c = 0; c < d->nbcomp; c++) { b += t * d->comp[c].hs * d->comp[c].vs; if (b % 64) return false; }
+      return true;
+   };
+   if (!getenv("JPEGGPU_TARGET_BLOCKS") && !wave_uniform(T) && T * 2 * per_mcu <= kMaxThreads && wave_uniform(T * 2)) T *= 2;
    // a frame narrower than the tile keeps a power-of-two tile (the unused lanes idle): the sub-sampling-specific
    // kernels turn the item index into (row, quad) with a shift and a mask
    while (T / 2 >= d->nbmcuH && T > 1) T /= 2;
    if (const char *e = getenv("JPEGGPU_TILE_MCUS")) {   // tuning knob: any T with T*blocks_per_MCU <= 256 (not a power of two: generic kernel)
       uint32_t v = (uint32_t)atoi(e);
-      if (v >= 1 && v * per_mcu <= 256) T = v;
+      if (v >= 1 && v * per_mcu <= kMaxThreads) T = v;
    }
    p.T = T; p.B = T * per_mcu;
    p.nbcomp = d->nbcomp; p.apply_iquant = d->apply_iquant; p.width = d->width;

@@ -6,6 +6,11 @@
 
 namespace jpeggpu_k {
 
+#ifndef JM_MAX_THREADS
+#define JM_MAX_THREADS 384
+#endif
+constexpr uint32_t kMaxThreads = JM_MAX_THREADS;   // __launch_bounds__ of the fused kernel = most blocks per tile
+
 // One launch of the fused back end: a batch of same-geometry frames, cut into tiles of
 // T MCUs x 1 MCU row.  Filled by plan_backend() in capi.cpp.
 struct BackendParams {

@@ -413,16 +413,18 @@ __device__ __forceinline__ void backend_body(const BackendParams &p) {
 #endif
 }
 
-template <int HFC, int VFC>
-__global__ void __launch_bounds__(256, JM_WAVES_PER_EU) backend_kernel(const BackendParams p) { backend_body<HFC, VFC, false>(p); }
+// Two launch bounds per sub-sampling: most tiles are <= 256 blocks; 6-block MCUs use 384 (capi.cpp, plan_backend).
+// Same body; the bound only changes the compiler's scheduling (the 256 build is ~1% faster where it applies).
+template <int HFC, int VFC, int MAXT>
+__global__ void __launch_bounds__(MAXT, JM_WAVES_PER_EU) backend_kernel(const BackendParams p) { backend_body<HFC, VFC, false>(p); }
 
 // the "-f" variant: generic pixel phase, no occupancy target (the direct transform keeps the block in 64 VGPRs)
-__global__ void __launch_bounds__(256) backend_kernel_slow(const BackendParams p) { backend_body<0, 0, true>(p); }
+__global__ void __launch_bounds__(JM_MAX_THREADS) backend_kernel_slow(const BackendParams p) { backend_body<0, 0, true>(p); }
 
 typedef void (*BackendFn)(const BackendParams);
-static BackendFn pick_kernel(const BackendParams &p) {
+static BackendFn pick_kernel(const BackendParams &p, uint32_t threads) {
    if (p.slow_coef) return (BackendFn)backend_kernel_slow;
-#define JM_PICK(H, V) ((BackendFn)backend_kernel<H, V>)
+#define JM_PICK(H, V) (threads <= 256 ? (BackendFn)backend_kernel<H, V, 256> : (BackendFn)backend_kernel<H, V, JM_MAX_THREADS>)
    if (p.nbcomp == 3 && p.wq_shift != 0xFFFFFFFFu && p.hf[0] == 1 && p.vf[0] == 1 && p.hf[1] == p.hf[2] && p.vf[1] == p.vf[2]) {
       const uint32_t h = p.hf[1], v = p.vf[1];
       if (h == 1 && v == 1) return JM_PICK(1, 1);
@@ -436,7 +438,8 @@ static BackendFn pick_kernel(const BackendParams &p) {
 
 hipError_t launch_backend(const BackendParams &p, const LaunchDims &d, hipStream_t s) {
    dim3 grid(d.tiles_per_row, d.mcu_rows, d.frames), block(d.threads);
-   BackendFn k = pick_kernel(p);
+   if (d.threads > JM_MAX_THREADS) return hipErrorInvalidConfiguration;
+   BackendFn k = pick_kernel(p, d.threads);
    if (d.lds_bytes > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d.lds_bytes);
       if (e != hipSuccess) return e;
