@@ -113,6 +113,18 @@ JM_HD uint2 pack_row_biased(const float (&x)[8]) {
    uint2 w;
 #if defined(__HIP_DEVICE_COMPILE__)
    const float x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3], x4 = x[4], x5 = x[5], x6 = x[6], x7 = x[7];
+#if defined(JM_DIAG_NOSETREG)   // timing experiment only (results are rounded, not truncated)
+   asm volatile("v_cvt_pk_u8_f32 %0, %2, 0, 0\n\t"
+                "v_cvt_pk_u8_f32 %1, %6, 0, 0\n\t"
+                "v_cvt_pk_u8_f32 %0, %3, 1, %0\n\t"
+                "v_cvt_pk_u8_f32 %1, %7, 1, %1\n\t"
+                "v_cvt_pk_u8_f32 %0, %4, 2, %0\n\t"
+                "v_cvt_pk_u8_f32 %1, %8, 2, %1\n\t"
+                "v_cvt_pk_u8_f32 %0, %5, 3, %0\n\t"
+                "v_cvt_pk_u8_f32 %1, %9, 3, %1"
+                : "=&v"(w.x), "=&v"(w.y)
+                : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(x6), "v"(x7));
+#else
    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
                 "s_nop 1\n\t"
                 "v_cvt_pk_u8_f32 %0, %2, 0, 0\n\t"
@@ -127,6 +139,7 @@ JM_HD uint2 pack_row_biased(const float (&x)[8]) {
                 "s_nop 1"
                 : "=&v"(w.x), "=&v"(w.y)
                 : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(x6), "v"(x7));
+#endif
 #else
    w.x = to_u8_biased(x[0]) | (to_u8_biased(x[1]) << 8) | (to_u8_biased(x[2]) << 16) | (to_u8_biased(x[3]) << 24);
    w.y = to_u8_biased(x[4]) | (to_u8_biased(x[5]) << 8) | (to_u8_biased(x[6]) << 16) | (to_u8_biased(x[7]) << 24);
