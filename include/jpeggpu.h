@@ -114,7 +114,8 @@ size_t jpeggpu_raster_row_bytes(const jpeggpu_frame_desc_t *desc);
  * out     : raster, jpeggpu_raster_rows() rows of jpeggpu_raster_row_bytes() bytes, row r at
  *           out + r*out_stride.  Exactly the bytes save_mcu_ligne_bw / save_mcu_ligne_color
  *           fwrite after the PPM/PGM header (src/decoder_utils.c:48-90).  out_stride == 0 means
- *           packed rows (the file layout).
+ *           packed rows (the file layout).  Any alignment; at most 2^26 bytes (the kernel reaches a
+ *           tile's rows with 32-bit offsets), larger strides return JPEGGPU_ERR_INVALID_ARG.
  *
  * Host-pointer form: pinned staging + hipMemcpyAsync H2D, one fused kernel, D2H, synchronous.  */
 int jpeggpu_backend_run(const jpeggpu_frame_desc_t *desc,

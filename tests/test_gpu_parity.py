@@ -123,6 +123,32 @@ def test_out_stride_and_untouched_padding(gpu):
     assert np.all(got[:, 903:] == 0xAB)
 
 
+def test_out_stride_limit(gpu):
+    d = helpers.to_gpu_desc(gpu, helpers.oracle_desc(64, 64, ((1, 1),) * 3))
+    with pytest.raises(Exception, match="out_stride"):
+        gpu.backend_run_device(d, [4096, 4096, 4096], QT, 4096, out_stride=(1 << 26) + 4)   # rejected before any access
+
+
+@pytest.mark.parametrize("env", [{"JPEGGPU_NO_UNIFORM": "1"}, {"JPEGGPU_TILE_MCUS": "21"}, {"JPEGGPU_TILE_MCUS": "5"},
+                                 {"JPEGGPU_TARGET_BLOCKS": "128"}], ids=lambda e: "_".join(f"{k[8:]}{v}" for k, v in e.items()))
+def test_other_tilings_and_prologues(gpu, env):
+    """The per-lane prologue (components sharing a wave, tables through LDS) and tiles that are not a power of
+    two wide (generic pixel phase) stay bit-exact: the tuning knobs select them."""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        for samp in (((1, 1),) * 3, ((2, 2), (1, 1), (1, 1)), ((2, 1), (1, 1), (1, 1)), ((1, 1),)):
+            d = helpers.oracle_desc(1500 + 8 * len(samp), 70, samp)
+            planes = helpers.synth_planes(d, 99, kind=1)
+            assert np.array_equal(orc.backend_run(d, planes, QT), gpu.backend_run(helpers.to_gpu_desc(gpu, d), planes, QT)), samp
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_full_int16_range_and_wrap(gpu):
     d = helpers.oracle_desc(640, 64, ((2, 2), (1, 1), (1, 1)), idq=[2, 2, 2])
     planes = helpers.synth_planes(d, 7, kind=2)
