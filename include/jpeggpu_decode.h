@@ -103,6 +103,22 @@ int  jpeggpu_out_file_name(const char *filepath, const char *outfile, uint8_t nb
  * (src/progressive.c:332-343).  *nb_images receives the number of images written.                */
 int  jpeggpu_jpeg2ppm(const char *filepath, const char *outfile, int *nb_images);
 
+/* The stages the reference times under -t (print_timer, src/timer.c:36-45; call sites src/jpeg2ppm.c:84-94,
+ * :134-135, src/baseline.c:224-228, src/progressive.c:316-321), for this library's decomposition of the work.
+ * Host wall-clock seconds.  gpu_wait_s is the time the host thread spent enqueuing uploads/launches and
+ * waiting for rasters; for progressive files most GPU work hides behind the entropy decoding of the next
+ * scan, so the parts do not add up to the GPU's busy time.                                          */
+typedef struct jpeggpu_timing_s {
+   double init_s;      /* binding the GPU (HIP runtime start-up, stream): first call of the process only        */
+   double header_s;    /* "Décodage entête" + the headers between scans                                   */
+   double vld_s;       /* "Décodage DC/AC et Quantification" (entropy decoding only; iquant runs on the GPU) */
+   double gpu_wait_s;  /* upload + kernel + download as seen by the host thread (IZZ + IDCT + colour)      */
+   double write_s;     /* "Ecriture de l'image"                                                           */
+   double total_s;     /* "Temps total"                                                                   */
+} jpeggpu_timing_t;
+/* jpeggpu_jpeg2ppm with the stage times; timing may be NULL.                                             */
+int  jpeggpu_jpeg2ppm_timed(const char *filepath, const char *outfile, int *nb_images, jpeggpu_timing_t *timing);
+
 /* ------------------------------------------------------------------------------------------ */
 /* Batches of independent images (BASELINE.json configs[4]: thousands of same-size files)        */
 /* ------------------------------------------------------------------------------------------ */

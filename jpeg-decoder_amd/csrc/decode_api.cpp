@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <string>
 
 #include "../../include/jpeggpu_decode.h"
@@ -342,6 +343,23 @@ int jpeggpu_out_file_name(const char *filepath, const char *outfile, uint8_t nbc
 }
 
 int jpeggpu_jpeg2ppm(const char *filepath, const char *outfile, int *nb_images) {
+   return jpeggpu_jpeg2ppm_timed(filepath, outfile, nb_images, nullptr);
+}
+
+int jpeggpu_jpeg2ppm_timed(const char *filepath, const char *outfile, int *nb_images, jpeggpu_timing_t *timing) {
+   using clk = std::chrono::steady_clock;
+   jpeggpu_timing_t tm = {0, 0, 0, 0, 0, 0};
+   const clk::time_point t_start = clk::now();
+   // adds the wall time of a stage to its accumulator when it goes out of scope
+   struct Lap {
+      double &acc; clk::time_point t0;
+      explicit Lap(double &a) : acc(a), t0(clk::now()) {}
+      ~Lap() { acc += std::chrono::duration<double>(clk::now() - t0).count(); }
+   };
+   struct Total {   // fills *timing on every exit path
+      jpeggpu_timing_t &tm; jpeggpu_timing_t *out; clk::time_point t0;
+      ~Total() { tm.total_s = std::chrono::duration<double>(clk::now() - t0).count(); if (out) *out = tm; }
+   } total{tm, timing, t_start};
    if (nb_images) *nb_images = 0;
    // verif_option_io, src/jpeg2ppm.c:25-60
    if (!filepath) { jpeggpu_internal_set_error("Pas de fichier jpeg/jpg"); return JPEGGPU_ERR_INVALID_FILE_PATH; }
@@ -358,7 +376,9 @@ int jpeggpu_jpeg2ppm(const char *filepath, const char *outfile, int *nb_images) 
       if (stat(folder.c_str(), &sb) == -1) mkdir(folder.c_str(), S_IRWXU | S_IRGRP | S_IXGRP | S_IROTH | S_IXOTH);
    }
    jpeggpu_jpeg_t *j = nullptr;
-   int rc = jpeggpu_jpeg_open_file(filepath, &j);
+   int rc;
+   { Lap lap(tm.init_s); (void)jpeggpu_internal_ensure_init(); }   // a missing device is reported by the first stage that needs it
+   { Lap lap(tm.header_s); rc = jpeggpu_jpeg_open_file(filepath, &j); }
    if (rc) return rc;
    jpeggpu_frame_desc_t desc;
    fill_desc(j->d, &desc);
@@ -369,13 +389,15 @@ int jpeggpu_jpeg2ppm(const char *filepath, const char *outfile, int *nb_images) 
       // decode_baseline_image, src/baseline.c:89-231: the output file exists (header + the complete MCU
       // rows) even when the scan turns out to be corrupt
       std::string name = out_name(filepath, outfile, desc.nbcomp, 0);
-      int drc = report(j, j->d.decode_scan());
+      int drc;
+      { Lap lap(tm.vld_s); drc = report(j, j->d.decode_scan()); }
       std::string derr = j->d.err;
       size_t rows = drc ? (size_t)j->d.mcu_rows_done * desc.max_v * 8 : jpeggpu_raster_rows(&desc);
       if (drc) for (int c = 0; c < desc.nbcomp; c++) j->d.dirty[c] = true;
       rc = 0;
-      if (rows && rb) { rc = render_begin(j); if (!rc) rc = render_end(j); }
+      if (rows && rb) { Lap lap(tm.gpu_wait_s); rc = render_begin(j); if (!rc) rc = render_end(j); }
       if (!rc) {
+         Lap lap(tm.write_s);
          rc = write_pnm(name.c_str(), &desc, j->h_out, rb, rows);
          if (rc) jpeggpu_internal_set_error(g_derr);
          else written = 1;
@@ -387,23 +409,30 @@ int jpeggpu_jpeg2ppm(const char *filepath, const char *outfile, int *nb_images) 
       std::string pending_name;
       auto flush = [&]() -> int {   // wait for the queued render and write its file
          if (pending_name.empty()) return 0;
-         int r = render_end(j);
-         if (!r) { r = write_pnm(pending_name.c_str(), &desc, j->h_out, rb, jpeggpu_raster_rows(&desc)); if (r) jpeggpu_internal_set_error(g_derr); else written++; }
+         int r;
+         { Lap lap(tm.gpu_wait_s); r = render_end(j); }
+         if (!r) {
+            Lap lap(tm.write_s);
+            r = write_pnm(pending_name.c_str(), &desc, j->h_out, rb, jpeggpu_raster_rows(&desc));
+            if (r) jpeggpu_internal_set_error(g_derr); else written++;
+         }
          pending_name.clear();
          return r;
       };
       while (!j->d.eoi_done) {
-         int drc = report(j, j->d.decode_scan());       // overlaps the kernel + download of the previous scan
+         int drc;
+         { Lap lap(tm.vld_s); drc = report(j, j->d.decode_scan()); }   // overlaps the kernel + download of the previous scan
          std::string derr = j->d.err;
          rc = flush();
          if (drc) { jpeggpu_internal_set_error(derr.c_str()); rc = drc; }
          if (rc) break;
-         rc = render_begin(j);
+         { Lap lap(tm.gpu_wait_s); rc = render_begin(j); }
          if (rc) break;
          pending_name = out_name(filepath, outfile, desc.nbcomp, (uint8_t)k);   // uint8_t parameter, src/utils.c:56
-         rc = render_planes_free(j);
+         { Lap lap(tm.gpu_wait_s); rc = render_planes_free(j); }
          if (rc) break;
-         int hrc = report(j, j->d.next_header());
+         int hrc;
+         { Lap lap(tm.header_s); hrc = report(j, j->d.next_header()); }
          if (hrc) { std::string herr = j->d.err; rc = flush(); jpeggpu_internal_set_error(herr.c_str()); rc = hrc; break; }
          k++;
       }

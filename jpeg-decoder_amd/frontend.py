@@ -153,6 +153,24 @@ def jpeg2ppm(filepath, outfile=None):
     return n.value
 
 
+class Timing(C.Structure):
+    """jpeggpu_timing_t: host wall-clock seconds of the stages the reference times under -t."""
+    _fields_ = [("init_s", C.c_double), ("header_s", C.c_double), ("vld_s", C.c_double), ("gpu_wait_s", C.c_double),
+                ("write_s", C.c_double), ("total_s", C.c_double)]
+
+
+lib.jpeggpu_jpeg2ppm_timed.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(Timing)]
+lib.jpeggpu_jpeg2ppm_timed.restype = C.c_int
+
+
+def jpeg2ppm_timed(filepath, outfile=None):
+    """jpeg2ppm that also returns the stage times: (images written, Timing)."""
+    n, t = C.c_int(0), Timing()
+    B._check(lib.jpeggpu_jpeg2ppm_timed(str(filepath).encode(), None if outfile is None else str(outfile).encode(),
+                                        C.byref(n), C.byref(t)))
+    return n.value, t
+
+
 class Blob(C.Structure):
     _fields_ = [("data", _vp), ("len", _sz)]
 

@@ -64,6 +64,23 @@ def test_command_line_driver(gpu, tmp_path, name):
     _check_outputs(out, e)
 
 
+def test_timer_option_and_timed_entry(gpu, tmp_path):
+    """-t prints one line per stage in print_timer's format (src/timer.c:43) and the files are unchanged."""
+    from jpeg_decoder_amd import frontend as F
+    exe = os.path.join(helpers.ROOT, "jpeg-decoder_amd", "jpeg2ppm_gpu")
+    name = "c4_prog422_160x120.jpg"
+    out = tmp_path / "o"
+    r = subprocess.run([exe, "-t", "-o", str(out / "x.pnm"), os.path.join(JDIR, name)], capture_output=True, timeout=120)
+    assert r.returncode == EXPECT[name]["rc"]
+    lines = r.stdout.decode().strip().split("\n")
+    assert len(lines) == 6 and lines[1].startswith("Décodage entête : ") and lines[-1].startswith("Temps total : ")
+    assert all(l.endswith(" s") and float(l.rsplit(" : ", 1)[1][:-2]) >= 0 for l in lines)
+    _check_outputs(out, EXPECT[name])
+    n, t = F.jpeg2ppm_timed(os.path.join(JDIR, name), tmp_path / "p" / "y.pnm")
+    assert n == sum(1 for o in EXPECT[name]["outputs"] if "link" not in o)
+    assert t.total_s > 0 and t.total_s >= t.vld_s and t.init_s + t.header_s + t.vld_s + t.gpu_wait_s + t.write_s <= t.total_s * 1.001
+
+
 def test_default_output_name_next_to_input(gpu, tmp_path):
     from jpeg_decoder_amd import frontend as F
     src = tmp_path / "img.jpeg"
