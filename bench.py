@@ -25,10 +25,10 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARC
 
 WORKLOADS = {
     # name: (description, width, height, sampling, frames per step)
-    "c2": ("4096x4096 4:4:4 baseline colour, synthetic coefficients (BASELINE.json configs[1])", 4096, 4096, ((1, 1),) * 3, 4),
-    "c3": ("8192x8192 4:2:0, 2x2 chroma upsampling fused into colour convert (configs[2])", 8192, 8192, ((2, 2), (1, 1), (1, 1)), 2),
-    "c4": ("4096x4096 4:2:2, GPU part of the progressive config (configs[3])", 4096, 4096, ((2, 1), (1, 1), (1, 1)), 6),
-    "c5": ("batch of 1920x1080 4:2:0 images (configs[4], per-GPU slice)", 1920, 1080, ((2, 2), (1, 1), (1, 1)), 64),
+    "c2": ("4096x4096 4:4:4 baseline colour, synthetic coefficients (BASELINE.json configs[1])", 4096, 4096, ((1, 1),) * 3, 16),
+    "c3": ("8192x8192 4:2:0, 2x2 chroma upsampling fused into colour convert (configs[2])", 8192, 8192, ((2, 2), (1, 1), (1, 1)), 8),
+    "c4": ("4096x4096 4:2:2, GPU part of the progressive config (configs[3])", 4096, 4096, ((2, 1), (1, 1), (1, 1)), 16),
+    "c5": ("batch of 1920x1080 4:2:0 images (configs[4], per-GPU slice)", 1920, 1080, ((2, 2), (1, 1), (1, 1)), 256),
 }
 
 
