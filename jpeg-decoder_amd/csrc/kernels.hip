@@ -2,16 +2,15 @@
 //
 // backend_kernel: the fused path  iquant + izz + idct_opt + upsample + ycc2rgb + raster store.
 //   One workgroup = one tile of T MCUs in one MCU row; one thread = one 8x8 block.
-//   phase 0  coalesced 16-byte loads of the tile's blocl16_t records -> LDS (XOR-swizzled so that
-//            the per-thread 128-byte reads of phase 1 are bank-conflict free)
-//   phase 1  each thread pulls its 64 coefficients into registers, dequantises, and runs both
-//            1-D passes of the Loeffler IDCT in registers (the inverse zigzag and the transpose
-//            between the passes are register renamings, not data movement), then writes its
-//            8 rows of 8 samples into the component's raster plane in LDS (aliasing the
-//            coefficient staging area, which is dead by then)
-//   phase 2  threads walk the tile's pixels 4 at a time: replicate-upsampled chroma fetch
-//            (px = x/hf, py = y/vf, src/decoder_utils.c:72-80), integer colour conversion, and
-//            12-byte coalesced stores into the RGB raster (width cropped, rows not).
+//   phase 1  each lane loads its own 128-byte blocl16_t record straight into registers (8 x 16 bytes),
+//            dequantises (table words as scalar operands when the wave holds one component), and runs both
+//            1-D passes of the Loeffler IDCT in registers (the inverse zigzag and the transpose between the
+//            passes are register renamings, not data movement), then writes its 8 rows of 8 samples into
+//            the component's u8 raster plane in LDS
+//   phase 2  after the one barrier the threads walk the tile's pixels 4 at a time: replicate-upsampled
+//            chroma fetch (px = x/hf, py = y/vf, src/decoder_utils.c:72-80), packed 16-bit integer colour
+//            conversion, and 12-byte coalesced non-temporal stores into the RGB raster (width cropped,
+//            rows not).
 //
 // Compiled with -ffp-contract=off (see jpeg_math.hpp).
 #include <hip/hip_runtime.h>
