@@ -67,7 +67,7 @@ def cpu_baseline(name, w, h, samp, qt, budget_s=12.0):
         be.backend_run(sd, planes, qt)
         reps += 1
         dt = time.perf_counter() - t0
-        if dt > budget_s * 0.6 or reps >= 64:
+        if dt > budget_s * 0.85 or reps >= 64:
             break
     pix = reps * w * min(h, nrows * rows_px)
     return {"value": round(pix / dt / 1e6, 2), "unit": "MPix/s", "cores": 1, "kind": kind,
