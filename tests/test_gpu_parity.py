@@ -176,6 +176,30 @@ def test_special_chroma_pair_reaches_the_fused_kernel(gpu):
     assert np.array_equal(gpu.backend_run(helpers.to_gpu_desc(gpu, d), planes, QT), want)
 
 
+@pytest.mark.parametrize("samp", [((1, 1),) * 3, ((2, 2), (1, 1), (1, 1)), ((2, 1), (1, 1), (1, 1)), ((1, 2), (1, 1), (1, 1))],
+                         ids=["444", "420", "422", "440"])
+def test_every_chroma_pair_through_the_fused_kernel(gpu, samp):
+    """All 65 536 (cb, cr) pairs, one per MCU as flat chroma blocks, under textured luma: the packed colour
+    path of each sub-sampling-specific pixel phase against the oracle (the special pair included)."""
+    hs, vs = samp[0]
+    d = helpers.oracle_desc(256 * 8 * hs, 256 * 8 * vs, samp, apply_iquant=False)
+    assert d.nbmcuH == 256 and d.nbmcuV == 256
+    planes = [pyoracle.synth_blocks(helpers.plane_shape(d, 0)[0], 1234, 0, 0)]
+    planes[0][:, 0] = np.clip(planes[0][:, 0] * 12, -1100, 1100)          # luma spread over the whole range
+    mcu = np.arange(65536)
+    for c, val in ((1, mcu % 256), (2, mcu // 256)):                      # MCU (row j, column i): cb = i, cr = j
+        pl = np.zeros(helpers.plane_shape(d, c), np.int16)
+        pl[:, 0] = (val - 128) * 8 + 4                                    # flat block of exactly `val`
+        planes.append(pl)
+    want = orc.backend_run(d, planes, QT)
+    got = gpu.backend_run(helpers.to_gpu_desc(gpu, d), planes, QT)
+    assert np.array_equal(got, want)
+    # the chroma blocks really are flat and cover 0..255: check through a grey-luma rendering of one MCU row
+    flat = [np.zeros_like(planes[0])] + planes[1:]
+    row = orc.backend_run(d, flat, QT, mcu_rows=(128, 129))[128 * 8 * vs]
+    assert len(np.unique(row.reshape(-1, 3)[:, 2])) >= 140                # blue follows cb across the row (clamped at both ends)
+
+
 # ---- BASELINE.json sizes: stripes vs the oracle + size-independent properties -------------------
 
 BIG = {"c2_4096x4096_444": (4096, 4096, ((1, 1),) * 3), "c3_8192x8192_420": (8192, 8192, ((2, 2), (1, 1), (1, 1))),
