@@ -28,6 +28,7 @@ WORKLOADS = {
     "c2": ("4096x4096 4:4:4 baseline colour, synthetic coefficients (BASELINE.json configs[1])", 4096, 4096, ((1, 1),) * 3, 16),
     "c3": ("8192x8192 4:2:0, 2x2 chroma upsampling fused into colour convert (configs[2])", 8192, 8192, ((2, 2), (1, 1), (1, 1)), 8),
     "c4": ("4096x4096 4:2:2, GPU part of the progressive config (configs[3])", 4096, 4096, ((2, 1), (1, 1), (1, 1)), 16),
+    "g1": ("8192x8192 grayscale (save_mcu_ligne_bw path; not a BASELINE config, gray coverage only)", 8192, 8192, ((1, 1),), 8),
     "c5": ("batch of 1920x1080 4:2:0 images (configs[4], per-GPU slice)", 1920, 1080, ((2, 2), (1, 1), (1, 1)), 256),
 }
 

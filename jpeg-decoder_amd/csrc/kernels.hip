@@ -104,6 +104,33 @@ __device__ __forceinline__ void pixel_phase(const BackendParams &p, const uint8_
    const uint32_t pitch0 = p.bw[0] * 8;
    if (p.nbcomp == 1) {
       // save_mcu_ligne_bw (src/decoder_utils.c:48-63): straight copy of the luma plane
+#if !defined(JM_GRAY_QUADS)
+      if (p.wq_shift != 0xFFFFFFFFu && wq >= 4) {
+         // power-of-two tile: 16 pixels per item, the item index is the plane's 16-byte word index
+         const uint32_t ws = p.wq_shift - 2;
+         const uint32_t nit = p.tile_rows << ws;
+         const uint32_t rem = p.width - x0;
+         uint8_t *tile_out = out + x0;
+         const uint32_t stride = (uint32_t)p.out_stride;
+         for (uint32_t it = tid; it < nit; it += nt) {
+            const uint32_t yi = it >> ws, x = (it & ((wq >> 2) - 1)) * 16;
+            if (x >= rem) continue;
+            const uint32_t left = rem - x;
+            const uint4 v = *reinterpret_cast<const uint4 *>(lds + p.plane_off[0] + it * 16);
+            uint8_t *dst = tile_out + (yi * stride + x);
+            if (left >= 16) {
+               typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+               __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4 __attribute__((aligned(JM_STORE_ALIGN))) *>(dst));
+            } else {
+               const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+               for (uint32_t i = 0; i < 15; i++)
+                  if (i < left) dst[i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
+            }
+         }
+         return;
+      }
+#endif
       for (uint32_t it = tid; it < nitems; it += nt) {
          const uint32_t y = iy, x = ix * 4;
          iy += dy; ix += dx;
