@@ -80,10 +80,33 @@ typedef struct jpeggpu_frame_desc_s {
 /* Library state                                                                               */
 /* ------------------------------------------------------------------------------------------ */
 
-/* Binds the calling process to HIP device <device> (one process per GPU) and creates the
- * library's stream and staging buffers.  Idempotent.  No counterpart in the reference.        */
+/* Creates the DEFAULT context on HIP device <device>: the stream, staging buffers and "-f" option that the
+ * process-wide entry points below (jpeggpu_backend_run ...) use.  Idempotent; a second device is refused
+ * here -- further devices, or several independent callers on one device, take contexts of their own
+ * (jpeggpu_ctx_create).  The first process-wide call without a prior jpeggpu_init() binds device 0.
+ * No counterpart in the reference (one thread, no device).                                          */
 int  jpeggpu_init(int device);
+/* Destroys the default context.  Not to be called while another thread is inside the library.      */
 void jpeggpu_shutdown(void);
+
+/* Per-device context ("our handle is per-device, one host thread per GPU, streams inside").
+ * The reference keeps its state in one global, all_option (src/options.c:13), and runs one thread
+ * (src/jpeg2ppm.c:62-138); a C caller that drives several GPUs from one process, or several threads on
+ * one GPU, gives each its own context: own stream, own staging buffers, own idct_fast option, own
+ * "-f" coefficient table.
+ *
+ * Threading contract.  HIP's current device is a per-thread setting: EVERY entry point of this library
+ * binds the calling thread to its context's device first (hipSetDevice), so any thread may call in.
+ * A context serialises its host-pointer entries internally (they share its staging buffers); the
+ * device-pointer entries only enqueue work and may be called concurrently.  Destroying a context
+ * while another thread uses it is the caller's bug.                                                 */
+typedef struct jpeggpu_ctx_s jpeggpu_ctx_t;
+int  jpeggpu_ctx_create(int device, jpeggpu_ctx_t **ctx);
+void jpeggpu_ctx_destroy(jpeggpu_ctx_t *ctx);
+int  jpeggpu_ctx_device(const jpeggpu_ctx_t *ctx);
+/* all_option.idct_fast of this context (src/options.c:76-79): starts as the process-wide value.     */
+void jpeggpu_ctx_set_idct_fast(jpeggpu_ctx_t *ctx, int fast);
+int  jpeggpu_ctx_get_idct_fast(const jpeggpu_ctx_t *ctx);
 /* Text of the last error raised on the calling thread ("" if none).  Stands in for erreur_t.com
  * (include/erreur.h:81-86).                                                                    */
 const char *jpeggpu_last_error(void);
@@ -117,7 +140,9 @@ size_t jpeggpu_raster_row_bytes(const jpeggpu_frame_desc_t *desc);
  *           packed rows (the file layout).  Any alignment; at most 2^26 bytes (the kernel reaches a
  *           tile's rows with 32-bit offsets), larger strides return JPEGGPU_ERR_INVALID_ARG.
  *
- * Host-pointer form: pinned staging + hipMemcpyAsync H2D, one fused kernel, D2H, synchronous.  */
+ * Host-pointer form, synchronous: the frame is cut into stripes of whole MCU rows that alternate between two
+ * streams, so that the upload of one stripe, the kernel of the previous and the download of the one before
+ * overlap (pinned hipMemcpyAsync both ways; see jpeggpu_host_register below).                            */
 int jpeggpu_backend_run(const jpeggpu_frame_desc_t *desc,
                         const jpeggpu_blocl16_t *const coef[3],
                         const jpeggpu_qtable_t *const qtables[4],
@@ -143,6 +168,29 @@ int jpeggpu_backend_run_batch_device(const jpeggpu_frame_desc_t *desc, uint32_t 
 
 /* Blocks until everything queued on <hip_stream> (NULL = library stream) has finished.         */
 int jpeggpu_synchronize(void *hip_stream);
+
+/* The same four calls on a context of the caller's (replacing the same reference loop,
+ * src/progressive.c:257-312 / src/baseline.c:160-217); hip_stream == NULL means the context's stream.  */
+int jpeggpu_ctx_backend_run(jpeggpu_ctx_t *ctx, const jpeggpu_frame_desc_t *desc,
+                            const jpeggpu_blocl16_t *const coef[3], const jpeggpu_qtable_t *const qtables[4],
+                            uint8_t *out, size_t out_stride);
+int jpeggpu_ctx_backend_run_device(jpeggpu_ctx_t *ctx, const jpeggpu_frame_desc_t *desc,
+                                   const void *const d_coef[3], const jpeggpu_qtable_t *const qtables[4],
+                                   void *d_out, size_t out_stride, void *hip_stream);
+int jpeggpu_ctx_backend_run_batch_device(jpeggpu_ctx_t *ctx, const jpeggpu_frame_desc_t *desc, uint32_t nframes,
+                                         const void *const d_coef[3], const size_t coef_frame_stride[3],
+                                         const jpeggpu_qtable_t *const qtables[4],
+                                         void *d_out, size_t out_stride, size_t out_frame_stride,
+                                         void *hip_stream);
+int jpeggpu_ctx_synchronize(jpeggpu_ctx_t *ctx, void *hip_stream);
+
+/* Pins caller memory in place (hipHostRegister).  jpeggpu_backend_run moves planes and rasters that are
+ * pinned -- by this call, by hipHostRegister or by hipHostMalloc -- with the DMA engines directly; pageable
+ * memory (what the reference's calloc gives, src/progressive.c:73-84) goes through pinned stripe buffers.
+ * Register once per buffer, not per call: pinning costs about as much as copying.  No counterpart in
+ * the reference.                                                                                        */
+int jpeggpu_host_register(void *ptr, size_t bytes);
+int jpeggpu_host_unregister(void *ptr);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Stage-level array forms of the four function contracts (host pointers, synchronous).        */

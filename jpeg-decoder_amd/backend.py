@@ -87,6 +87,20 @@ lib.jpeggpu_idct_coef_table.argtypes = [_vp]
 lib.jpeggpu_idct_coef_table.restype = None
 lib.jpeggpu_set_idct_fast.argtypes = [C.c_int]
 lib.jpeggpu_set_idct_fast.restype = None
+lib.jpeggpu_ctx_create.argtypes = [C.c_int, C.POINTER(_vp)]
+lib.jpeggpu_ctx_destroy.argtypes = [_vp]
+lib.jpeggpu_ctx_destroy.restype = None
+lib.jpeggpu_ctx_device.argtypes = [_vp]
+lib.jpeggpu_ctx_set_idct_fast.argtypes = [_vp, C.c_int]
+lib.jpeggpu_ctx_set_idct_fast.restype = None
+lib.jpeggpu_ctx_get_idct_fast.argtypes = [_vp]
+lib.jpeggpu_ctx_backend_run.argtypes = [_vp] + lib.jpeggpu_backend_run.argtypes
+lib.jpeggpu_ctx_backend_run_device.argtypes = [_vp] + lib.jpeggpu_backend_run_device.argtypes
+lib.jpeggpu_ctx_backend_run_batch_device.argtypes = [_vp] + lib.jpeggpu_backend_run_batch_device.argtypes
+lib.jpeggpu_ctx_synchronize.argtypes = [_vp, _vp]
+lib.jpeggpu_host_register.argtypes = [_vp, _sz]
+lib.jpeggpu_host_unregister.argtypes = [_vp]
+lib.jpeggpu_internal_reload_tuning.restype = None
 
 
 def last_error():
@@ -149,7 +163,22 @@ def _qt_array(qtables):
     return ptrs, keep
 
 
-def backend_run(desc, coef, qtables, out=None, out_stride=0):
+def reload_tuning():
+    """The JPEGGPU_* tuning knobs are read from the environment once; tests and tools that change them inside one
+    process ask for them to be read again."""
+    lib.jpeggpu_internal_reload_tuning()
+
+
+def host_register(arr):
+    """jpeggpu_host_register on a numpy array's memory (pinned in place until host_unregister)."""
+    _check(lib.jpeggpu_host_register(arr.ctypes.data, arr.nbytes))
+
+
+def host_unregister(arr):
+    _check(lib.jpeggpu_host_unregister(arr.ctypes.data))
+
+
+def backend_run(desc, coef, qtables, out=None, out_stride=0, ctx=None):
     """jpeggpu_backend_run: host planes in, host raster out (rows x row_bytes uint8)."""
     nc = desc.nbcomp if desc.nbcomp in (1, 3) else min(len(coef), 3)
     planes = [np.ascontiguousarray(coef[c], dtype=np.int16) for c in range(min(nc, len(coef)))]
@@ -161,26 +190,70 @@ def backend_run(desc, coef, qtables, out=None, out_stride=0):
     stride = out_stride or rb
     if out is None:
         out = np.zeros((max(rows, 1), max(stride, 1)), dtype=np.uint8)
-    _check(lib.jpeggpu_backend_run(C.byref(desc), cp, qp, out.ctypes.data, out_stride))
+    if ctx is not None:
+        _check(lib.jpeggpu_ctx_backend_run(ctx.handle, C.byref(desc), cp, qp, out.ctypes.data, out_stride))
+    else:
+        _check(lib.jpeggpu_backend_run(C.byref(desc), cp, qp, out.ctypes.data, out_stride))
     return out[:rows, :stride]
 
 
-def backend_run_device(desc, d_coef, qtables, d_out, out_stride=0, stream=None):
+def backend_run_device(desc, d_coef, qtables, d_out, out_stride=0, stream=None, ctx=None):
     """Device pointers (ints) in, asynchronous on `stream` (a hipStream_t as int, None = library stream)."""
     cp = (_vp * 3)(*[int(p) if p else None for p in list(d_coef) + [None] * (3 - len(d_coef))])
     qp, keep = _qt_array(qtables)
-    _check(lib.jpeggpu_backend_run_device(C.byref(desc), cp, qp, _vp(int(d_out)), out_stride, _vp(stream or 0)))
+    if ctx is not None:
+        _check(lib.jpeggpu_ctx_backend_run_device(ctx.handle, C.byref(desc), cp, qp, _vp(int(d_out)), out_stride, _vp(stream or 0)))
+    else:
+        _check(lib.jpeggpu_backend_run_device(C.byref(desc), cp, qp, _vp(int(d_out)), out_stride, _vp(stream or 0)))
 
 
 def backend_run_batch_device(desc, nframes, d_coef, coef_frame_stride, qtables, d_out, out_stride=0,
-                             out_frame_stride=0, stream=None):
+                             out_frame_stride=0, stream=None, ctx=None):
     cp = (_vp * 3)(*[int(p) if p else None for p in list(d_coef) + [None] * (3 - len(d_coef))])
     fs = None
     if coef_frame_stride is not None:
         fs = (_sz * 3)(*(list(coef_frame_stride) + [0] * (3 - len(coef_frame_stride))))
     qp, keep = _qt_array(qtables)
-    _check(lib.jpeggpu_backend_run_batch_device(C.byref(desc), nframes, cp, fs, qp, _vp(int(d_out)), out_stride,
-                                                out_frame_stride, _vp(stream or 0)))
+    if ctx is not None:
+        _check(lib.jpeggpu_ctx_backend_run_batch_device(ctx.handle, C.byref(desc), nframes, cp, fs, qp, _vp(int(d_out)), out_stride,
+                                                        out_frame_stride, _vp(stream or 0)))
+    else:
+        _check(lib.jpeggpu_backend_run_batch_device(C.byref(desc), nframes, cp, fs, qp, _vp(int(d_out)), out_stride,
+                                                    out_frame_stride, _vp(stream or 0)))
+
+
+class Context:
+    """jpeggpu_ctx_t: a per-device context (own stream, staging and idct_fast option).  Pass it as ctx= to the
+    backend_run* functions; one per host thread that drives a GPU."""
+
+    def __init__(self, device=0):
+        h = _vp()
+        _check(lib.jpeggpu_ctx_create(int(device), C.byref(h)))
+        self.handle = h
+
+    @property
+    def device(self):
+        return lib.jpeggpu_ctx_device(self.handle)
+
+    def set_idct_fast(self, fast):
+        lib.jpeggpu_ctx_set_idct_fast(self.handle, 1 if fast else 0)
+
+    def get_idct_fast(self):
+        return bool(lib.jpeggpu_ctx_get_idct_fast(self.handle))
+
+    def synchronize(self, stream=None):
+        _check(lib.jpeggpu_ctx_synchronize(self.handle, _vp(stream or 0)))
+
+    def close(self):
+        if self.handle:
+            lib.jpeggpu_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 def iquant_blocks(blocks, s_start, s_end, qtable):

@@ -24,6 +24,7 @@
 
 extern "C" void jpeggpu_internal_set_error(const char *msg);
 extern "C" int jpeggpu_internal_ensure_init(void);
+extern "C" int jpeggpu_internal_device(void);
 
 namespace {
 
@@ -206,8 +207,7 @@ extern "C" int jpeggpu_decode_batch(const jpeggpu_blob_t *jpegs, size_t n, uint8
       // tasks of chunk k-1 (staging only).  The copy tasks sit at the end of the list, so the threads reach
       // them when the GPU has long finished chunk k-1; the first one to get there waits for its event.
       std::atomic<int> hip_error{ 0 };
-      int dev = 0;
-      (void)hipGetDevice(&dev);
+      const int dev = jpeggpu_internal_device();   // the default context's device, not whatever this thread happens to be bound to
       for (size_t k = 0; k <= nchunks; k++) {
          const int b = (int)(k % nbuf);
          const bool have_chunk = k < nchunks;
@@ -230,7 +230,7 @@ extern "C" int jpeggpu_decode_batch(const jpeggpu_blob_t *jpegs, size_t n, uint8
          pool.run(cnt + pcnt, [&](size_t task) {
             if (task >= cnt) {                          // ---- copy-out of image (task - cnt) of the previous chunk
                const size_t i = task - cnt;
-               (void)hipSetDevice(dev);                 // worker threads start on device 0
+               (void)hipSetDevice(dev);                 // HIP's current device is per thread: workers start on device 0
                if (hipEventSynchronize(pev) != hipSuccess) { hip_error.store(1); return; }
                memcpy(rasters + (pbase + i) * raster_frame_stride, psrc + i * out_bytes, out_bytes);
                return;

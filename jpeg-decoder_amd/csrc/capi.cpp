@@ -1,10 +1,12 @@
 // capi.cpp -- the C-ABI layer declared in include/jpeggpu.h.
 //
 // Host-side logic only: argument validation with the reference's error convention, tile planning,
-// pinned staging for the host-pointer forms, and kernel launches.  No pixel arithmetic lives here
-// and there is no CPU fallback: every entry point that produces data needs a HIP device.
+// per-device contexts (stream, staging, "-f" table, option), the pipelined host-pointer form, and kernel
+// launches.  No pixel arithmetic lives here and there is no CPU fallback: every entry point that
+// produces data needs a HIP device.
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -16,6 +18,23 @@
 #include "kernels.h"
 
 using namespace jpeggpu_k;
+
+// One context per device and caller: its own stream, staging and option.  The process-wide entry points
+// of the header (jpeggpu_backend_run ...) run on a default context bound by jpeggpu_init().
+struct jpeggpu_ctx_s {
+   int device = -1;
+   hipStream_t stream = nullptr;                 // default stream of the context (device-pointer forms with hip_stream == NULL)
+   hipStream_t pipe[2] = { nullptr, nullptr };   // the two lanes of the host-pointer pipeline
+   hipEvent_t pipe_done[2] = { nullptr, nullptr };
+   std::mutex mu;                                // host-pointer and stage-level entries: they share the staging below
+   void *d_in = nullptr;  size_t d_in_cap = 0;
+   void *d_out = nullptr; size_t d_out_cap = 0;
+   void *h_in[2] = { nullptr, nullptr };  size_t h_in_cap[2] = { 0, 0 };     // pinned stripe staging
+   void *h_out[2] = { nullptr, nullptr }; size_t h_out_cap[2] = { 0, 0 };
+   std::atomic<int> idct_fast{ 1 };              // all_option.idct_fast of this context
+   std::mutex slow_mu;
+   std::atomic<float *> d_slow_coef{ nullptr };  // calc_coef's table on the device, built on first use
+};
 
 namespace {
 
@@ -29,31 +48,99 @@ int fail(int code, const char *fmt, ...) {
    return code;
 }
 
-struct State {
-   bool ready = false;
-   int device = -1;
-   hipStream_t stream = nullptr;
-   uint32_t num_cus = 256;
-   // device + pinned staging for the host-pointer entry points, grown on demand
-   void *d_in = nullptr;  size_t d_in_cap = 0;
-   void *d_out = nullptr; size_t d_out_cap = 0;
-   void *h_pin = nullptr; size_t h_pin_cap = 0;
-   // "-f" mode (all_option.idct_fast == 0): calc_coef's table on the device, built on first use
-   bool idct_fast = true;
-   float *d_slow_coef = nullptr;
-};
-State g;
-std::mutex g_mu;
-
 #define HIP_TRY(expr)                                                                            \
    do {                                                                                          \
       hipError_t e_ = (expr);                                                                    \
       if (e_ != hipSuccess) return fail(JPEGGPU_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
    } while (0)
 
-int ensure_init() {
-   if (g.ready) return 0;
-   return jpeggpu_init(0);
+// ---- tuning knobs: read from the environment ONCE (first use), never per launch --------------------
+struct Tuning {
+   uint32_t target_blocks = 0;   // JPEGGPU_TARGET_BLOCKS (0 = default 256)
+   uint32_t tile_mcus = 0;       // JPEGGPU_TILE_MCUS: any T (not a power of two: generic pixel phase)
+   bool no_uniform = false;      // JPEGGPU_NO_UNIFORM: per-lane prologue everywhere
+   bool no_linear = false;       // JPEGGPU_NO_LINEAR: tiles never run on over the end of an MCU row
+   size_t stripe_bytes = 0;      // JPEGGPU_STRIPE_BYTES: stripe size of the host-pointer pipeline
+   size_t diag_lds_bytes = 0;    // JPEGGPU_DIAG_LDS_BYTES: larger LDS allocation = fewer resident workgroups per CU
+};
+Tuning g_tune;
+std::once_flag g_tune_once;
+
+void read_tuning() {
+   Tuning t;
+   if (const char *e = getenv("JPEGGPU_TARGET_BLOCKS")) t.target_blocks = (uint32_t)atoi(e);
+   if (const char *e = getenv("JPEGGPU_TILE_MCUS")) t.tile_mcus = (uint32_t)atoi(e);
+   t.no_uniform = getenv("JPEGGPU_NO_UNIFORM") != nullptr;
+   t.no_linear = getenv("JPEGGPU_NO_LINEAR") != nullptr;
+   if (const char *e = getenv("JPEGGPU_STRIPE_BYTES")) t.stripe_bytes = (size_t)atoll(e);
+   if (const char *e = getenv("JPEGGPU_DIAG_LDS_BYTES")) t.diag_lds_bytes = (size_t)atol(e);
+   g_tune = t;
+}
+const Tuning &tuning() { std::call_once(g_tune_once, read_tuning); return g_tune; }
+
+// ---- contexts ----------------------------------------------------------------------------------------
+std::mutex g_mu;                        // creation / destruction of the default context
+std::atomic<jpeggpu_ctx_s *> g_default{ nullptr };
+std::atomic<int> g_idct_fast{ 1 };      // the process-wide option (jpeggpu_set_idct_fast); survives jpeggpu_shutdown
+
+int ctx_new(int device, jpeggpu_ctx_s **out) {
+   int n = 0;
+   hipError_t e = hipGetDeviceCount(&n);
+   if (e != hipSuccess || n <= 0) return fail(JPEGGPU_ERR_NO_DEVICE, "no HIP device (%s)", e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+   if (device < 0 || device >= n) return fail(JPEGGPU_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, n);
+   HIP_TRY(hipSetDevice(device));
+   jpeggpu_ctx_s *c = new jpeggpu_ctx_s;
+   c->device = device;
+   hipError_t rc = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+   for (int i = 0; i < 2 && rc == hipSuccess; i++) {
+      rc = hipStreamCreateWithFlags(&c->pipe[i], hipStreamNonBlocking);
+      if (rc == hipSuccess) rc = hipEventCreateWithFlags(&c->pipe_done[i], hipEventDisableTiming);
+   }
+   if (rc != hipSuccess) {
+      for (int i = 0; i < 2; i++) { if (c->pipe_done[i]) (void)hipEventDestroy(c->pipe_done[i]); if (c->pipe[i]) (void)hipStreamDestroy(c->pipe[i]); }
+      if (c->stream) (void)hipStreamDestroy(c->stream);
+      delete c;
+      return fail(JPEGGPU_ERR_HIP, "stream/event creation on device %d: %s", device, hipGetErrorString(rc));
+   }
+   c->idct_fast.store(g_idct_fast.load());
+   *out = c;
+   return 0;
+}
+
+void ctx_delete(jpeggpu_ctx_s *c) {
+   if (!c) return;
+   (void)hipSetDevice(c->device);
+   (void)hipStreamSynchronize(c->stream);
+   for (int i = 0; i < 2; i++) {
+      (void)hipStreamSynchronize(c->pipe[i]);
+      if (c->h_in[i]) (void)hipHostFree(c->h_in[i]);
+      if (c->h_out[i]) (void)hipHostFree(c->h_out[i]);
+      (void)hipEventDestroy(c->pipe_done[i]);
+      (void)hipStreamDestroy(c->pipe[i]);
+   }
+   if (c->d_in) (void)hipFree(c->d_in);
+   if (c->d_out) (void)hipFree(c->d_out);
+   if (float *t = c->d_slow_coef.load()) (void)hipFree(t);
+   (void)hipStreamDestroy(c->stream);
+   delete c;
+}
+
+// HIP's current device is a per-THREAD setting: every entry point binds the calling thread to the context's device.
+int bind(jpeggpu_ctx_s *c) {
+   if (!c) return fail(JPEGGPU_ERR_INVALID_ARG, "ctx is NULL");
+   HIP_TRY(hipSetDevice(c->device));
+   return 0;
+}
+
+int default_ctx(jpeggpu_ctx_s **out) {
+   jpeggpu_ctx_s *c = g_default.load();
+   if (!c) {
+      int rc = jpeggpu_init(0);
+      if (rc) return rc;
+      c = g_default.load();
+   }
+   *out = c;
+   return bind(c);
 }
 
 int grow(void **p, size_t *cap, size_t need, bool pinned) {
@@ -85,12 +172,22 @@ void calc_coef_host(float *t) {
             }
 }
 
-int ensure_slow_coef() {
-   if (g.d_slow_coef) return 0;
-   static float table[4096];
-   calc_coef_host(table);
-   HIP_TRY(hipMalloc((void **)&g.d_slow_coef, sizeof table));
-   HIP_TRY(hipMemcpy(g.d_slow_coef, table, sizeof table, hipMemcpyHostToDevice));
+int ensure_slow_coef(jpeggpu_ctx_s *c, const float **out) {
+   float *t = c->d_slow_coef.load(std::memory_order_acquire);
+   if (!t) {
+      std::lock_guard<std::mutex> lk(c->slow_mu);
+      t = c->d_slow_coef.load(std::memory_order_relaxed);
+      if (!t) {
+         static float table[4096];
+         static std::once_flag once;
+         std::call_once(once, [] { calc_coef_host(table); });
+         HIP_TRY(hipMalloc((void **)&t, sizeof table));
+         hipError_t e = hipMemcpy(t, table, sizeof table, hipMemcpyHostToDevice);
+         if (e != hipSuccess) { (void)hipFree(t); return fail(JPEGGPU_ERR_HIP, "upload of the idct table: %s", hipGetErrorString(e)); }
+         c->d_slow_coef.store(t, std::memory_order_release);
+      }
+   }
+   *out = t;
    return 0;
 }
 
@@ -107,7 +204,6 @@ int validate(const jpeggpu_frame_desc_t *d, const jpeggpu_qtable_t *const qt[4])
    if (d->width == 0 || d->nbmcuH == 0 || d->nbmcuV == 0 || d->max_h == 0 || d->max_v == 0)
       return fail(JPEGGPU_ERR_INVALID_ARG, "empty geometry (width=%u nbmcuH=%u nbmcuV=%u max_h=%u max_v=%u)", d->width, d->nbmcuH,
                   d->nbmcuV, d->max_h, d->max_v);
-   uint32_t per_mcu = 0;
    for (int c = 0; c < d->nbcomp; c++) {
       const jpeggpu_component_t &k = d->comp[c];
       if (k.hs == 0 || k.vs == 0 || k.hs > 4 || k.vs > 4)
@@ -116,23 +212,20 @@ int validate(const jpeggpu_frame_desc_t *d, const jpeggpu_qtable_t *const qt[4])
          return fail(JPEGGPU_ERR_SAMPLING, "component %d: %ux%u does not divide max %ux%u", c, k.hs, k.vs, d->max_h, d->max_v);
       if (d->apply_iquant && (k.idq > 3 || !qt || !qt[k.idq]))
          return fail(JPEGGPU_ERR_NO_QT, "Pas de table de quantification pour la composante %d", c);
-      per_mcu += (uint32_t)k.hs * k.vs;
    }
    if ((uint64_t)d->nbmcuH * d->max_h * 8 < d->width)
       return fail(JPEGGPU_ERR_INVALID_ARG, "width %u exceeds nbmcuH*max_h*8 = %llu", d->width,
                   (unsigned long long)d->nbmcuH * d->max_h * 8);
-   (void)per_mcu;
    return 0;
 }
 
-
 // Tile planning: T MCUs per workgroup, one thread per block.
 void plan_backend(const jpeggpu_frame_desc_t *d, const jpeggpu_qtable_t *const qt[4], BackendParams &p, LaunchDims &ld) {
+   const Tuning &tn = tuning();
    memset(&p, 0, sizeof p);
    uint32_t per_mcu = 0;
    for (int c = 0; c < d->nbcomp; c++) per_mcu += (uint32_t)d->comp[c].hs * d->comp[c].vs;
-   uint32_t target_blocks = 256;
-   if (const char *e = getenv("JPEGGPU_TARGET_BLOCKS")) target_blocks = (uint32_t)atoi(e);   // tuning knob
+   uint32_t target_blocks = tn.target_blocks ? tn.target_blocks : 256;
    if (target_blocks < 48) target_blocks = 48;          // one MCU can hold 3 * 4*4 blocks
    if (target_blocks > kMaxThreads) target_blocks = kMaxThreads;   // __launch_bounds__
    // T MCUs per tile: the largest power of two that fits the block budget (4:4:4 -> 64 MCUs = 192
@@ -146,14 +239,11 @@ void plan_backend(const jpeggpu_frame_desc_t *d, const jpeggpu_qtable_t *const q
       for (int c = 0; c < d->nbcomp; c++) { b += t * d->comp[c].hs * d->comp[c].vs; if (b % 64) return false; }
       return true;
    };
-   if (!getenv("JPEGGPU_TARGET_BLOCKS") && !wave_uniform(T) && T * 2 * per_mcu <= kMaxThreads && wave_uniform(T * 2)) T *= 2;
+   if (!tn.target_blocks && !wave_uniform(T) && T * 2 * per_mcu <= kMaxThreads && wave_uniform(T * 2)) T *= 2;
    // a frame narrower than the tile keeps a power-of-two tile (the unused lanes idle): the sub-sampling-specific
    // kernels turn the item index into (row, quad) with a shift and a mask
    while (T / 2 >= d->nbmcuH && T > 1) T /= 2;
-   if (const char *e = getenv("JPEGGPU_TILE_MCUS")) {   // tuning knob: any T with T*blocks_per_MCU <= 256 (not a power of two: generic kernel)
-      uint32_t v = (uint32_t)atoi(e);
-      if (v >= 1 && v * per_mcu <= kMaxThreads) T = v;
-   }
+   if (tn.tile_mcus >= 1 && tn.tile_mcus * per_mcu <= kMaxThreads) T = tn.tile_mcus;
    p.T = T; p.B = T * per_mcu;
    p.nbcomp = d->nbcomp; p.apply_iquant = d->apply_iquant; p.width = d->width;
    p.tile_w = T * d->max_h * 8; p.tile_rows = (uint32_t)d->max_v * 8;
@@ -172,7 +262,7 @@ void plan_backend(const jpeggpu_frame_desc_t *d, const jpeggpu_qtable_t *const q
    p.wave_uniform = 1;
    for (int c = 1; c <= d->nbcomp; c++)
       if (p.boff[c] % 64) p.wave_uniform = 0;
-   if (getenv("JPEGGPU_NO_UNIFORM")) p.wave_uniform = 0;   // diagnostic: per-lane prologue everywhere
+   if (tn.no_uniform) p.wave_uniform = 0;
    if (d->apply_iquant)
       for (int i = 0; i < 4; i++)
          if (qt[i]) pack_qtable(qt[i], p.qt[i]);
@@ -180,13 +270,10 @@ void plan_backend(const jpeggpu_frame_desc_t *d, const jpeggpu_qtable_t *const q
    ld.mcu_rows = d->nbmcuV;
    ld.threads = (p.B + 63) / 64 * 64;                 // one thread per block
    ld.lds_bytes = (size_t)ld.threads * 64 + 512;
-   if (const char *e = getenv("JPEGGPU_DIAG_LDS_BYTES")) {   // diagnostic: larger allocation = fewer resident workgroups per CU
-      size_t v = (size_t)atol(e);
-      if (v > ld.lds_bytes && v <= 64 * 1024) ld.lds_bytes = v;
-   }
+   if (tn.diag_lds_bytes > ld.lds_bytes && tn.diag_lds_bytes <= 64 * 1024) ld.lds_bytes = tn.diag_lds_bytes;
 }
 
-int run_device(const jpeggpu_frame_desc_t *d, uint32_t nframes, const void *const d_coef[3], const size_t cfs[3],
+int run_device(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, uint32_t nframes, const void *const d_coef[3], const size_t cfs[3],
                const jpeggpu_qtable_t *const qt[4], void *d_out, size_t out_stride, size_t out_frame_stride, hipStream_t s) {
    BackendParams p; LaunchDims ld;
    plan_backend(d, qt, p, ld);
@@ -205,13 +292,114 @@ int run_device(const jpeggpu_frame_desc_t *d, uint32_t nframes, const void *cons
    }
    if (!d_out) return fail(JPEGGPU_ERR_INVALID_ARG, "out is NULL");
    p.out = d_out; p.out_stride = out_stride; p.out_frame_stride = out_frame_stride;
-   if (const char *e = getenv("JPEGGPU_DIAG_PTR")) p.diag = (void *)strtoull(e, nullptr, 0);   // diagnostic builds only
+#if defined(JM_DIAG_STAMP)   // diagnostic builds only (tools/stamp.py): where the kernel leaves its phase time stamps
+   if (const char *e = getenv("JPEGGPU_DIAG_PTR")) p.diag = (void *)strtoull(e, nullptr, 0);
+#endif
    if (nframes == 0) return 0;
-   if (!g.idct_fast) { int rc = ensure_slow_coef(); if (rc) return rc; p.slow_coef = g.d_slow_coef; }
+   if (!ctx->idct_fast.load()) { int rc = ensure_slow_coef(ctx, &p.slow_coef); if (rc) return rc; }   // the option is read ONCE per call
    if (nframes > 65535 || d->nbmcuV > 65535) return fail(JPEGGPU_ERR_INVALID_ARG, "nframes / nbmcuV above 65535");
    ld.frames = nframes;
    HIP_TRY(launch_backend(p, ld, s));
    return 0;
+}
+
+bool is_pinned_host(const void *p) {
+   hipPointerAttribute_t a;
+   if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+   return a.type == hipMemoryTypeHost;
+}
+
+// The host-pointer form.  The frame is cut into stripes of whole MCU rows (a stripe is a frame of its own to the
+// kernel: replicate upsampling has no halo, src/decoder_utils.c:72-80) that alternate between two streams, so the
+// upload of stripe k+1, the kernel of stripe k and the download of stripe k-1 overlap.  Caller memory that is already
+// pinned (hipHostMalloc, hipHostRegister / jpeggpu_host_register) is read and written by the DMA engines in place;
+// pageable memory (the reference's malloc'ed buffers, src/progressive.c:73-84) goes through two pinned stripe
+// buffers, filled and emptied by this thread while the other stripe is in flight.
+int run_host(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, const jpeggpu_blocl16_t *const coef[3], const jpeggpu_qtable_t *const qt[4],
+             uint8_t *out, size_t out_stride) {
+   const size_t row_bytes = jpeggpu_raster_row_bytes(d), rows = jpeggpu_raster_rows(d);
+   if (out_stride == 0) out_stride = row_bytes;
+   if (out_stride < row_bytes) return fail(JPEGGPU_ERR_INVALID_ARG, "out_stride %zu < row bytes %zu", out_stride, row_bytes);
+   std::lock_guard<std::mutex> lk(ctx->mu);
+   size_t plane_bytes[3] = { 0, 0, 0 }, off[3] = { 0, 0, 0 }, row_in[3] = { 0, 0, 0 }, in_bytes = 0, in_per_mcu_row = 0;
+   for (int c = 0; c < d->nbcomp; c++) {
+      plane_bytes[c] = jpeggpu_plane_blocks(d, c) * sizeof(jpeggpu_blocl16_t);
+      row_in[c] = (size_t)d->nbmcuH * d->comp[c].hs * d->comp[c].vs * sizeof(jpeggpu_blocl16_t);   // one MCU row of plane c
+      off[c] = in_bytes; in_bytes += plane_bytes[c]; in_per_mcu_row += row_in[c];
+   }
+   const size_t band = (size_t)d->max_v * 8;                 // raster rows per MCU row
+   const size_t out_bytes = row_bytes * rows;
+   int rc = grow(&ctx->d_in, &ctx->d_in_cap, in_bytes, false); if (rc) return rc;
+   rc = grow(&ctx->d_out, &ctx->d_out_cap, out_bytes, false); if (rc) return rc;
+   bool in_pinned = true;
+   for (int c = 0; c < d->nbcomp; c++) in_pinned = in_pinned && is_pinned_host(coef[c]);
+   const bool out_pinned = is_pinned_host(out);
+   // stripe height: ~8 MiB of coefficients, at least one MCU row, at most the frame
+   const size_t target = tuning().stripe_bytes ? tuning().stripe_bytes : ((size_t)8 << 20);
+   uint32_t srows = (uint32_t)(target / (in_per_mcu_row ? in_per_mcu_row : 1));
+   if (srows < 1) srows = 1;
+   if (srows > d->nbmcuV) srows = d->nbmcuV;
+   const uint32_t nstripes = (d->nbmcuV + srows - 1) / srows;
+   if (!in_pinned) for (int b = 0; b < 2; b++) { rc = grow(&ctx->h_in[b], &ctx->h_in_cap[b], (size_t)srows * in_per_mcu_row, true); if (rc) return rc; }
+   if (!out_pinned) for (int b = 0; b < 2; b++) { rc = grow(&ctx->h_out[b], &ctx->h_out_cap[b], (size_t)srows * band * row_bytes, true); if (rc) return rc; }
+
+   auto copy_out = [&](uint32_t k) {   // staged raster band of stripe k -> the caller's rows
+      const uint32_t m0 = k * srows, n = (m0 + srows <= d->nbmcuV ? srows : d->nbmcuV - m0);
+      const uint8_t *src = (const uint8_t *)ctx->h_out[k & 1];
+      uint8_t *dst = out + (size_t)m0 * band * out_stride;
+      if (out_stride == row_bytes) memcpy(dst, src, (size_t)n * band * row_bytes);
+      else for (size_t r = 0; r < (size_t)n * band; r++) memcpy(dst + r * out_stride, src + r * row_bytes, row_bytes);
+   };
+   bool queued[2] = { false, false };
+   for (uint32_t k = 0; k < nstripes; k++) {
+      const int b = (int)(k & 1);
+      hipStream_t s = ctx->pipe[b];
+      const uint32_t m0 = k * srows, n = (m0 + srows <= d->nbmcuV ? srows : d->nbmcuV - m0);
+      if (queued[b] && (!in_pinned || !out_pinned)) {   // stripe k-2 used the same staging buffers
+         HIP_TRY(hipEventSynchronize(ctx->pipe_done[b]));
+         if (!out_pinned) copy_out(k - 2);
+         queued[b] = false;
+      }
+      const void *dc[3] = { nullptr, nullptr, nullptr };
+      size_t hoff = 0;
+      for (int c = 0; c < d->nbcomp; c++) {
+         const char *src = (const char *)coef[c] + (size_t)m0 * row_in[c];
+         char *dst = (char *)ctx->d_in + off[c] + (size_t)m0 * row_in[c];
+         if (!in_pinned) {
+            memcpy((char *)ctx->h_in[b] + hoff, src, (size_t)n * row_in[c]);
+            src = (const char *)ctx->h_in[b] + hoff;
+            hoff += (size_t)n * row_in[c];
+         }
+         HIP_TRY(hipMemcpyAsync(dst, src, (size_t)n * row_in[c], hipMemcpyHostToDevice, s));
+         dc[c] = dst;
+      }
+      jpeggpu_frame_desc_t sd = *d;
+      sd.nbmcuV = n;
+      uint8_t *d_band = (uint8_t *)ctx->d_out + (size_t)m0 * band * row_bytes;
+      rc = run_device(ctx, &sd, 1, dc, nullptr, qt, d_band, row_bytes, 0, s); if (rc) return rc;
+      if (!out_pinned) HIP_TRY(hipMemcpyAsync(ctx->h_out[b], d_band, (size_t)n * band * row_bytes, hipMemcpyDeviceToHost, s));
+      else if (out_stride == row_bytes) HIP_TRY(hipMemcpyAsync(out + (size_t)m0 * band * row_bytes, d_band, (size_t)n * band * row_bytes, hipMemcpyDeviceToHost, s));
+      else HIP_TRY(hipMemcpy2DAsync(out + (size_t)m0 * band * out_stride, out_stride, d_band, row_bytes, row_bytes, (size_t)n * band, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipEventRecord(ctx->pipe_done[b], s));
+      queued[b] = true;
+   }
+   // drain, oldest stripe first
+   for (uint32_t k = (nstripes >= 2 ? nstripes - 2 : 0); k < nstripes; k++) {
+      const int b = (int)(k & 1);
+      if (!queued[b]) continue;
+      HIP_TRY(hipEventSynchronize(ctx->pipe_done[b]));
+      if (!out_pinned) copy_out(k);
+      queued[b] = false;
+   }
+   return 0;
+}
+
+int ctx_backend_run(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, const jpeggpu_blocl16_t *const coef[3],
+                    const jpeggpu_qtable_t *const qt[4], uint8_t *out, size_t out_stride) {
+   int rc = validate(d, qt); if (rc) return rc;
+   if (!out) return fail(JPEGGPU_ERR_INVALID_ARG, "out is NULL");
+   for (int c = 0; c < d->nbcomp; c++) if (!coef || !coef[c]) return fail(JPEGGPU_ERR_INVALID_ARG, "coef[%d] is NULL", c);
+   return run_host(ctx, d, coef, qt, out, out_stride);
 }
 
 }  // namespace
@@ -220,38 +408,44 @@ extern "C" {
 
 const char *jpeggpu_last_error(void) { return g_err; }
 
-// used by decode_api.cpp (same library); not part of the public headers
+// used by decode_api.cpp / batch_api.cpp (same library); not part of the public headers
 void jpeggpu_internal_set_error(const char *msg) { snprintf(g_err, sizeof g_err, "%s", msg ? msg : ""); }
-int jpeggpu_internal_ensure_init(void) { return ensure_init(); }
+int jpeggpu_internal_ensure_init(void) { jpeggpu_ctx_s *c; return default_ctx(&c); }   // also binds the calling thread to the device
+int jpeggpu_internal_device(void) { jpeggpu_ctx_s *c = g_default.load(); return c ? c->device : 0; }
+// tests and tools change the knobs inside one process: they ask for the environment to be read again
+void jpeggpu_internal_reload_tuning(void) { (void)tuning(); read_tuning(); }
 
 int jpeggpu_init(int device) {
    std::lock_guard<std::mutex> lk(g_mu);
-   if (g.ready && g.device == device) return 0;
-   if (g.ready) return fail(JPEGGPU_ERR_INVALID_ARG, "already bound to device %d (one process per GPU)", g.device);
-   int n = 0;
-   hipError_t e = hipGetDeviceCount(&n);
-   if (e != hipSuccess || n <= 0) return fail(JPEGGPU_ERR_NO_DEVICE, "no HIP device (%s)", e == hipSuccess ? "count is 0" : hipGetErrorString(e));
-   if (device < 0 || device >= n) return fail(JPEGGPU_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, n);
-   HIP_TRY(hipSetDevice(device));
-   HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-   int cus = 0;
-   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) g.num_cus = (uint32_t)cus;
-   g.device = device; g.ready = true;
+   (void)tuning();
+   if (jpeggpu_ctx_s *c = g_default.load()) {
+      if (c->device == device) return bind(c);
+      return fail(JPEGGPU_ERR_INVALID_ARG, "the default context is bound to device %d; use jpeggpu_ctx_create() for further devices", c->device);
+   }
+   jpeggpu_ctx_s *c = nullptr;
+   int rc = ctx_new(device, &c);
+   if (rc) return rc;
+   g_default.store(c);
    g_err[0] = 0;
    return 0;
 }
 
 void jpeggpu_shutdown(void) {
    std::lock_guard<std::mutex> lk(g_mu);
-   if (!g.ready) return;
-   (void)hipStreamSynchronize(g.stream);
-   if (g.d_in) (void)hipFree(g.d_in);
-   if (g.d_out) (void)hipFree(g.d_out);
-   if (g.h_pin) (void)hipHostFree(g.h_pin);
-   if (g.d_slow_coef) (void)hipFree(g.d_slow_coef);
-   (void)hipStreamDestroy(g.stream);
-   g = State();
+   jpeggpu_ctx_s *c = g_default.exchange(nullptr);
+   ctx_delete(c);
 }
+
+int jpeggpu_ctx_create(int device, jpeggpu_ctx_t **ctx) {
+   if (!ctx) return fail(JPEGGPU_ERR_INVALID_ARG, "ctx is NULL");
+   *ctx = nullptr;
+   (void)tuning();
+   return ctx_new(device, ctx);
+}
+void jpeggpu_ctx_destroy(jpeggpu_ctx_t *ctx) { ctx_delete(ctx); }
+int jpeggpu_ctx_device(const jpeggpu_ctx_t *ctx) { return ctx ? ctx->device : -1; }
+void jpeggpu_ctx_set_idct_fast(jpeggpu_ctx_t *ctx, int fast) { if (ctx) ctx->idct_fast.store(fast != 0); }
+int jpeggpu_ctx_get_idct_fast(const jpeggpu_ctx_t *ctx) { return ctx ? ctx->idct_fast.load() : -1; }
 
 int jpeggpu_frame_geometry(jpeggpu_frame_desc_t *d) {
    if (!d) return fail(JPEGGPU_ERR_INVALID_ARG, "desc is NULL");
@@ -277,19 +471,48 @@ size_t jpeggpu_plane_blocks(const jpeggpu_frame_desc_t *d, int c) {
 size_t jpeggpu_raster_rows(const jpeggpu_frame_desc_t *d) { return d ? (size_t)d->nbmcuV * d->max_v * 8 : 0; }
 size_t jpeggpu_raster_row_bytes(const jpeggpu_frame_desc_t *d) { return d ? (size_t)d->width * (d->nbcomp == 3 ? 3 : 1) : 0; }
 
-int jpeggpu_synchronize(void *hip_stream) {
-   int rc = ensure_init(); if (rc) return rc;
-   HIP_TRY(hipStreamSynchronize(hip_stream ? (hipStream_t)hip_stream : g.stream));
+// ---- per-context forms -------------------------------------------------------------------------------
+
+int jpeggpu_ctx_synchronize(jpeggpu_ctx_t *ctx, void *hip_stream) {
+   int rc = bind(ctx); if (rc) return rc;
+   HIP_TRY(hipStreamSynchronize(hip_stream ? (hipStream_t)hip_stream : ctx->stream));
    return 0;
+}
+
+int jpeggpu_ctx_backend_run_batch_device(jpeggpu_ctx_t *ctx, const jpeggpu_frame_desc_t *d, uint32_t nframes, const void *const d_coef[3],
+                                         const size_t coef_frame_stride[3], const jpeggpu_qtable_t *const qt[4], void *d_out,
+                                         size_t out_stride, size_t out_frame_stride, void *hip_stream) {
+   int rc = validate(d, qt); if (rc) return rc;
+   rc = bind(ctx); if (rc) return rc;
+   return run_device(ctx, d, nframes, d_coef, coef_frame_stride, qt, d_out, out_stride, out_frame_stride,
+                     hip_stream ? (hipStream_t)hip_stream : ctx->stream);
+}
+
+int jpeggpu_ctx_backend_run_device(jpeggpu_ctx_t *ctx, const jpeggpu_frame_desc_t *d, const void *const d_coef[3],
+                                   const jpeggpu_qtable_t *const qt[4], void *d_out, size_t out_stride, void *hip_stream) {
+   return jpeggpu_ctx_backend_run_batch_device(ctx, d, 1, d_coef, nullptr, qt, d_out, out_stride, 0, hip_stream);
+}
+
+int jpeggpu_ctx_backend_run(jpeggpu_ctx_t *ctx, const jpeggpu_frame_desc_t *d, const jpeggpu_blocl16_t *const coef[3],
+                            const jpeggpu_qtable_t *const qt[4], uint8_t *out, size_t out_stride) {
+   int rc = bind(ctx); if (rc) return rc;
+   return ctx_backend_run(ctx, d, coef, qt, out, out_stride);
+}
+
+// ---- process-wide forms: the same on the default context -------------------------------------------
+
+int jpeggpu_synchronize(void *hip_stream) {
+   jpeggpu_ctx_s *c; int rc = default_ctx(&c); if (rc) return rc;
+   return jpeggpu_ctx_synchronize(c, hip_stream);
 }
 
 int jpeggpu_backend_run_batch_device(const jpeggpu_frame_desc_t *d, uint32_t nframes, const void *const d_coef[3],
                                      const size_t coef_frame_stride[3], const jpeggpu_qtable_t *const qt[4], void *d_out,
                                      size_t out_stride, size_t out_frame_stride, void *hip_stream) {
-   int rc = validate(d, qt); if (rc) return rc;
-   rc = ensure_init(); if (rc) return rc;
-   return run_device(d, nframes, d_coef, coef_frame_stride, qt, d_out, out_stride, out_frame_stride,
-                     hip_stream ? (hipStream_t)hip_stream : g.stream);
+   int rc = validate(d, qt); if (rc) return rc;           // argument errors are reported without a device
+   jpeggpu_ctx_s *c; rc = default_ctx(&c); if (rc) return rc;
+   return run_device(c, d, nframes, d_coef, coef_frame_stride, qt, d_out, out_stride, out_frame_stride,
+                     hip_stream ? (hipStream_t)hip_stream : c->stream);
 }
 
 int jpeggpu_backend_run_device(const jpeggpu_frame_desc_t *d, const void *const d_coef[3], const jpeggpu_qtable_t *const qt[4],
@@ -302,43 +525,35 @@ int jpeggpu_backend_run(const jpeggpu_frame_desc_t *d, const jpeggpu_blocl16_t *
    int rc = validate(d, qt); if (rc) return rc;
    if (!out) return fail(JPEGGPU_ERR_INVALID_ARG, "out is NULL");
    for (int c = 0; c < d->nbcomp; c++) if (!coef || !coef[c]) return fail(JPEGGPU_ERR_INVALID_ARG, "coef[%d] is NULL", c);
-   rc = ensure_init(); if (rc) return rc;
-   std::lock_guard<std::mutex> lk(g_mu);
-   const size_t row_bytes = jpeggpu_raster_row_bytes(d), rows = jpeggpu_raster_rows(d);
-   if (out_stride == 0) out_stride = row_bytes;
-   if (out_stride < row_bytes) return fail(JPEGGPU_ERR_INVALID_ARG, "out_stride %zu < row bytes %zu", out_stride, row_bytes);
-   size_t off[3] = { 0, 0, 0 }, in_bytes = 0;
-   for (int c = 0; c < d->nbcomp; c++) { off[c] = in_bytes; in_bytes += jpeggpu_plane_blocks(d, c) * sizeof(jpeggpu_blocl16_t); }
-   const size_t out_bytes = row_bytes * rows;
-   rc = grow(&g.d_in, &g.d_in_cap, in_bytes, false); if (rc) return rc;
-   rc = grow(&g.d_out, &g.d_out_cap, out_bytes, false); if (rc) return rc;
-   rc = grow(&g.h_pin, &g.h_pin_cap, in_bytes > out_bytes ? in_bytes : out_bytes, true); if (rc) return rc;
-   // uploaded once with pinned hipMemcpyAsync (north star); the caller's buffers are pageable
-   // malloc memory (src/progressive.c:73-84), so they are gathered into the pinned area first.
-   const void *dc[3] = { nullptr, nullptr, nullptr };
-   for (int c = 0; c < d->nbcomp; c++) {
-      memcpy((char *)g.h_pin + off[c], coef[c], jpeggpu_plane_blocks(d, c) * sizeof(jpeggpu_blocl16_t));
-      dc[c] = (char *)g.d_in + off[c];
-   }
-   HIP_TRY(hipMemcpyAsync(g.d_in, g.h_pin, in_bytes, hipMemcpyHostToDevice, g.stream));
-   rc = run_device(d, 1, dc, nullptr, qt, g.d_out, row_bytes, 0, g.stream); if (rc) return rc;
-   HIP_TRY(hipMemcpyAsync(g.h_pin, g.d_out, out_bytes, hipMemcpyDeviceToHost, g.stream));
-   HIP_TRY(hipStreamSynchronize(g.stream));
-   for (size_t r = 0; r < rows; r++) memcpy(out + r * out_stride, (char *)g.h_pin + r * row_bytes, row_bytes);
+   jpeggpu_ctx_s *c; rc = default_ctx(&c); if (rc) return rc;
+   return run_host(c, d, coef, qt, out, out_stride);
+}
+
+// Pins caller memory in place so that jpeggpu_backend_run reads / writes it by DMA (no staging copy).
+int jpeggpu_host_register(void *ptr, size_t bytes) {
+   if (!ptr || !bytes) return fail(JPEGGPU_ERR_INVALID_ARG, "NULL argument");
+   jpeggpu_ctx_s *c; int rc = default_ctx(&c); if (rc) return rc;
+   HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+   return 0;
+}
+int jpeggpu_host_unregister(void *ptr) {
+   if (!ptr) return fail(JPEGGPU_ERR_INVALID_ARG, "NULL argument");
+   HIP_TRY(hipHostUnregister(ptr));
    return 0;
 }
 
 // ---- stage-level array forms -----------------------------------------------------------------
 
-static int stage_roundtrip(const void *in, size_t in_bytes, void *out, size_t out_bytes, hipError_t (*launch)(void *, void *, void *), void *ctx) {
-   int rc = ensure_init(); if (rc) return rc;
-   std::lock_guard<std::mutex> lk(g_mu);
-   rc = grow(&g.d_in, &g.d_in_cap, in_bytes, false); if (rc) return rc;
-   rc = grow(&g.d_out, &g.d_out_cap, out_bytes, false); if (rc) return rc;
-   HIP_TRY(hipMemcpyAsync(g.d_in, in, in_bytes, hipMemcpyHostToDevice, g.stream));
-   HIP_TRY(launch(g.d_in, g.d_out, ctx));
-   HIP_TRY(hipMemcpyAsync(out, out_bytes ? g.d_out : g.d_in, out_bytes ? out_bytes : in_bytes, hipMemcpyDeviceToHost, g.stream));
-   HIP_TRY(hipStreamSynchronize(g.stream));
+static int stage_roundtrip(const void *in, size_t in_bytes, void *out, size_t out_bytes,
+                           hipError_t (*launch)(void *, void *, void *, hipStream_t), void *arg) {
+   jpeggpu_ctx_s *c; int rc = default_ctx(&c); if (rc) return rc;
+   std::lock_guard<std::mutex> lk(c->mu);
+   rc = grow(&c->d_in, &c->d_in_cap, in_bytes, false); if (rc) return rc;
+   rc = grow(&c->d_out, &c->d_out_cap, out_bytes, false); if (rc) return rc;
+   HIP_TRY(hipMemcpyAsync(c->d_in, in, in_bytes, hipMemcpyHostToDevice, c->stream));
+   HIP_TRY(launch(c->d_in, c->d_out, arg, c->stream));
+   HIP_TRY(hipMemcpyAsync(out, out_bytes ? c->d_out : c->d_in, out_bytes ? out_bytes : in_bytes, hipMemcpyDeviceToHost, c->stream));
+   HIP_TRY(hipStreamSynchronize(c->stream));
    return 0;
 }
 
@@ -346,50 +561,57 @@ int jpeggpu_iquant_blocks(jpeggpu_blocl16_t *blocks, size_t n, uint8_t s_start, 
    if (n == 0) return 0;
    if (!blocks || !q) return fail(JPEGGPU_ERR_INVALID_ARG, "NULL argument");
    if (s_end > 63) return fail(JPEGGPU_ERR_INVALID_ARG, "s_end %u > 63", s_end);
-   struct Ctx { size_t n; int s0, s1; uint32_t q[32]; } ctx = { n, s_start, s_end, {} };
-   pack_qtable(q, ctx.q);
-   return stage_roundtrip(blocks, n * 128, blocks, 0, [](void *di, void *, void *c) {
-      Ctx *x = (Ctx *)c; return launch_iquant(di, x->n, x->s0, x->s1, x->q, g.stream); }, &ctx);
+   struct Arg { size_t n; int s0, s1; uint32_t q[32]; } arg = { n, s_start, s_end, {} };
+   pack_qtable(q, arg.q);
+   return stage_roundtrip(blocks, n * 128, blocks, 0, [](void *di, void *, void *a, hipStream_t s) {
+      Arg *x = (Arg *)a; return launch_iquant(di, x->n, x->s0, x->s1, x->q, s); }, &arg);
 }
 
 int jpeggpu_izz_blocks(const jpeggpu_blocl16_t *in, jpeggpu_bloct16_t *out, size_t n) {
    if (n == 0) return 0;
    if (!in || !out) return fail(JPEGGPU_ERR_INVALID_ARG, "NULL argument");
-   return stage_roundtrip(in, n * 128, out, n * 128, [](void *di, void *dout, void *c) { return launch_izz(di, dout, *(size_t *)c, g.stream); }, &n);
+   return stage_roundtrip(in, n * 128, out, n * 128, [](void *di, void *dout, void *a, hipStream_t s) { return launch_izz(di, dout, *(size_t *)a, s); }, &n);
 }
 
 int jpeggpu_idct_opt_blocks(const jpeggpu_bloct16_t *in, jpeggpu_bloctu8_t *out, size_t n) {
    if (n == 0) return 0;
    if (!in || !out) return fail(JPEGGPU_ERR_INVALID_ARG, "NULL argument");
-   return stage_roundtrip(in, n * 128, out, n * 64, [](void *di, void *dout, void *c) { return launch_idct(di, dout, *(size_t *)c, g.stream); }, &n);
+   return stage_roundtrip(in, n * 128, out, n * 64, [](void *di, void *dout, void *a, hipStream_t s) { return launch_idct(di, dout, *(size_t *)a, s); }, &n);
 }
 
 int jpeggpu_idct_blocks(const jpeggpu_bloct16_t *in, jpeggpu_bloctu8_t *out, size_t n) {
    if (n == 0) return 0;
    if (!in || !out) return fail(JPEGGPU_ERR_INVALID_ARG, "NULL argument");
-   int rc = ensure_init(); if (rc) return rc;
-   { std::lock_guard<std::mutex> lk(g_mu); rc = ensure_slow_coef(); if (rc) return rc; }
-   return stage_roundtrip(in, n * 128, out, n * 64, [](void *di, void *dout, void *c) { return launch_idct_slow(di, dout, *(size_t *)c, g.d_slow_coef, g.stream); }, &n);
+   jpeggpu_ctx_s *c; int rc = default_ctx(&c); if (rc) return rc;
+   struct Arg { size_t n; const float *coef; } arg = { n, nullptr };
+   rc = ensure_slow_coef(c, &arg.coef); if (rc) return rc;
+   return stage_roundtrip(in, n * 128, out, n * 64, [](void *di, void *dout, void *a, hipStream_t s) {
+      Arg *x = (Arg *)a; return launch_idct_slow(di, dout, x->n, x->coef, s); }, &arg);
 }
 
-void jpeggpu_set_idct_fast(int fast) { g.idct_fast = fast != 0; }
-int jpeggpu_get_idct_fast(void) { return g.idct_fast ? 1 : 0; }
+// all_option.idct_fast: process-wide in the reference (src/options.c:13,76-79).  Sets the default context's option and
+// the value every context created later starts with; kept across jpeggpu_shutdown().
+void jpeggpu_set_idct_fast(int fast) {
+   g_idct_fast.store(fast != 0);
+   if (jpeggpu_ctx_s *c = g_default.load()) c->idct_fast.store(fast != 0);
+}
+int jpeggpu_get_idct_fast(void) { return g_idct_fast.load(); }
 void jpeggpu_idct_coef_table(float *out4096) { if (out4096) calc_coef_host(out4096); }
 
 int jpeggpu_ycc2rgb_pixels(const uint8_t *y, const uint8_t *cb, const uint8_t *cr, jpeggpu_rgb_t *rgb, size_t n) {
    if (n == 0) return 0;
    if (!y || !cb || !cr || !rgb) return fail(JPEGGPU_ERR_INVALID_ARG, "NULL argument");
-   int rc = ensure_init(); if (rc) return rc;
-   std::lock_guard<std::mutex> lk(g_mu);
-   rc = grow(&g.d_in, &g.d_in_cap, 3 * n, false); if (rc) return rc;
-   rc = grow(&g.d_out, &g.d_out_cap, 3 * n, false); if (rc) return rc;
-   uint8_t *di = (uint8_t *)g.d_in;
-   HIP_TRY(hipMemcpyAsync(di, y, n, hipMemcpyHostToDevice, g.stream));
-   HIP_TRY(hipMemcpyAsync(di + n, cb, n, hipMemcpyHostToDevice, g.stream));
-   HIP_TRY(hipMemcpyAsync(di + 2 * n, cr, n, hipMemcpyHostToDevice, g.stream));
-   HIP_TRY(launch_ycc2rgb(di, di + n, di + 2 * n, (uint8_t *)g.d_out, n, g.stream));
-   HIP_TRY(hipMemcpyAsync(rgb, g.d_out, 3 * n, hipMemcpyDeviceToHost, g.stream));
-   HIP_TRY(hipStreamSynchronize(g.stream));
+   jpeggpu_ctx_s *c; int rc = default_ctx(&c); if (rc) return rc;
+   std::lock_guard<std::mutex> lk(c->mu);
+   rc = grow(&c->d_in, &c->d_in_cap, 3 * n, false); if (rc) return rc;
+   rc = grow(&c->d_out, &c->d_out_cap, 3 * n, false); if (rc) return rc;
+   uint8_t *di = (uint8_t *)c->d_in;
+   HIP_TRY(hipMemcpyAsync(di, y, n, hipMemcpyHostToDevice, c->stream));
+   HIP_TRY(hipMemcpyAsync(di + n, cb, n, hipMemcpyHostToDevice, c->stream));
+   HIP_TRY(hipMemcpyAsync(di + 2 * n, cr, n, hipMemcpyHostToDevice, c->stream));
+   HIP_TRY(launch_ycc2rgb(di, di + n, di + 2 * n, (uint8_t *)c->d_out, n, c->stream));
+   HIP_TRY(hipMemcpyAsync(rgb, c->d_out, 3 * n, hipMemcpyDeviceToHost, c->stream));
+   HIP_TRY(hipStreamSynchronize(c->stream));
    return 0;
 }
 

@@ -97,14 +97,13 @@ int alloc_planes(jpeggpu_jpeg *j) {
 }
 
 void free_all(jpeggpu_jpeg *j) {
-   if (j->gpu) {
-      if (j->stream) (void)hipStreamSynchronize(j->stream);
-      for (int c = 0; c < 3; c++) if (j->d_plane[c]) (void)hipFree(j->d_plane[c]);
-      if (j->d_out) (void)hipFree(j->d_out);
-      if (j->h_out) (void)hipHostFree(j->h_out);
-      if (j->uploaded) (void)hipEventDestroy(j->uploaded);
-      if (j->stream) (void)hipStreamDestroy(j->stream);
-   }
+   // every member is released on its own: a render that failed half-way through its allocations leaves some set
+   if (j->stream) (void)hipStreamSynchronize(j->stream);
+   for (int c = 0; c < 3; c++) if (j->d_plane[c]) (void)hipFree(j->d_plane[c]);
+   if (j->d_out) (void)hipFree(j->d_out);
+   if (j->h_out) (void)hipHostFree(j->h_out);
+   if (j->uploaded) (void)hipEventDestroy(j->uploaded);
+   if (j->stream) (void)hipStreamDestroy(j->stream);
    for (int c = 0; c < 3; c++)
       if (j->d.plane[c]) { if (j->pinned) (void)hipHostFree(j->d.plane[c]); else free(j->d.plane[c]); }
    delete j;
@@ -145,16 +144,16 @@ int render_begin(jpeggpu_jpeg *j) {
       }
    int rc = jpeggpu_internal_ensure_init();
    if (rc) return rc;
-   if (!j->gpu) {
-      HIP_TRYD(hipStreamCreateWithFlags(&j->stream, hipStreamNonBlocking));
-      HIP_TRYD(hipEventCreateWithFlags(&j->uploaded, hipEventDisableTiming));
+   if (!j->gpu) {   // allocate what is still missing (a retry after a failed attempt keeps what it already has)
+      if (!j->stream) HIP_TRYD(hipStreamCreateWithFlags(&j->stream, hipStreamNonBlocking));
+      if (!j->uploaded) HIP_TRYD(hipEventCreateWithFlags(&j->uploaded, hipEventDisableTiming));
       for (int c = 0; c < d.nbcomp; c++) {
-         HIP_TRYD(hipMalloc(&j->d_plane[c], j->plane_bytes[c] ? j->plane_bytes[c] : 128));
+         if (!j->d_plane[c]) HIP_TRYD(hipMalloc(&j->d_plane[c], j->plane_bytes[c] ? j->plane_bytes[c] : 128));
          d.dirty[c] = true;
       }
       j->out_bytes = jpeggpu_raster_rows(&desc) * jpeggpu_raster_row_bytes(&desc);
-      HIP_TRYD(hipMalloc(&j->d_out, j->out_bytes ? j->out_bytes : 16));
-      HIP_TRYD(hipHostMalloc((void **)&j->h_out, j->out_bytes ? j->out_bytes : 16, hipHostMallocDefault));
+      if (!j->d_out) HIP_TRYD(hipMalloc(&j->d_out, j->out_bytes ? j->out_bytes : 16));
+      if (!j->h_out) HIP_TRYD(hipHostMalloc((void **)&j->h_out, j->out_bytes ? j->out_bytes : 16, hipHostMallocDefault));
       j->gpu = true;
    }
    for (int c = 0; c < d.nbcomp; c++)

@@ -61,8 +61,8 @@ int HuffTable::build(const uint8_t counts[16], const uint8_t *symbols, unsigned 
             int c0 = (int)nodes.size();
             nodes.push_back(Node{ { -1, -1 }, 0 });
             nodes.push_back(Node{ { -1, -1 }, 0 });
-            nodes[nd].child[0] = (int16_t)c0;
-            nodes[nd].child[1] = (int16_t)(c0 + 1);
+            nodes[nd].child[0] = c0;
+            nodes[nd].child[1] = c0 + 1;
             next.push_back(c0);
             next.push_back(c0 + 1);
          }
@@ -72,12 +72,13 @@ int HuffTable::build(const uint8_t counts[16], const uint8_t *symbols, unsigned 
    }
    if (nsym == 0) leftover = true;    // the queue still holds the root
    if (!leftover) return JPEGGPU_ERR_HUFF_BAD;
+   if (nodes.size() > ((size_t)1 << 17)) return JPEGGPU_ERR_HUFF_BAD;   // cannot happen: depth <= 16 bounds the tree at 2^17 - 1 nodes
    // lookup tables
    for (unsigned w = 0; w < 512; w++) {
       int nd = 0, l = 0;
       while (l < 9 && nodes[nd].child[0] >= 0) { nd = nodes[nd].child[(w >> (8 - l)) & 1]; l++; }
       if (nodes[nd].child[0] < 0 && l > 0) { fast[w] = (uint16_t)((l << 8) | nodes[nd].sym); deep[w] = 0; }
-      else { fast[w] = 0; deep[w] = (int16_t)nd; }
+      else { fast[w] = 0; deep[w] = nd; }
    }
    present = true;
    return 0;

@@ -18,10 +18,12 @@ struct HuffTable {
    // Mirror of the breadth-first tree of remplir_huffman (src/entete.c:452-507): canonical codes, and
    // nodes that were created but never given a symbol stay leaves with symbol 0 (calloc), which
    // is what a corrupt stream decodes to in the reference.
-   struct Node { int16_t child[2]; uint8_t sym; };
+   // A table whose shortest code is 15 or 16 bits long makes the breadth-first build expand every node above
+   // that depth (up to 2^17 - 1 nodes), so node indices are 32-bit.
+   struct Node { int32_t child[2]; uint8_t sym; };
    std::vector<Node> nodes;
    uint16_t fast[512];   // (length << 8) | symbol for codes of <= 9 bits, else 0
-   int16_t deep[512];    // node reached after 9 bits when fast[] is 0
+   int32_t deep[512];    // node reached after 9 bits when fast[] is 0
    bool present = false;
    int build(const uint8_t counts[16], const uint8_t *symbols, unsigned nsym);   // 0 or ERR_HUFF_BAD
 };

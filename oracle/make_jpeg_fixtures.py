@@ -205,6 +205,44 @@ def main():
     add("bad_prog_short.jpg", prog[:sos[4]] + bytes([0xFF, 0xD9]), "file ends after four scans (still valid)")
     hdr_end = sos[5] + 2 + ((prog[sos[5] + 2] << 8) | prog[sos[5] + 3])
     add("bad_prog_ah_al.jpg", prog[:hdr_end - 1] + bytes([0x31]) + prog[hdr_end:], "refinement scan with Ah-Al = 2")
+    # Huffman tables whose SHORTEST code is 15 / 16 bits long: the breadth-first build (src/entete.c:454-509)
+    # expands every node above that depth (up to 2^17 - 1 nodes).  Hand-written 16x16 gray baseline files.
+    def tiny_gray(dc_counts, dc_syms, ac_counts, ac_syms, scan):
+        d = bytearray(b"\xFF\xD8\xFF\xE0\x00\x10JFIF\x00\x01\x01\x00\x00\x01\x00\x01\x00\x00")
+        d += b"\xFF\xDB\x00\x43\x00" + bytes(range(1, 65))
+        d += b"\xFF\xC0\x00\x0B\x08\x00\x10\x00\x10\x01\x01\x11\x00"
+        for tc, counts, syms in ((0x00, dc_counts, dc_syms), (0x10, ac_counts, ac_syms)):
+            d += b"\xFF\xC4" + (2 + 17 + len(syms)).to_bytes(2, "big") + bytes([tc]) + bytes(counts) + bytes(syms)
+        d += b"\xFF\xDA\x00\x08\x01\x01\x00\x00\x3F\x00" + bytes(scan) + b"\xFF\xD9"
+        return bytes(d)
+
+    def bits_to_bytes(bits):
+        bits = bits + "1" * (-len(bits) % 8)
+        out = bytearray()
+        for i in range(0, len(bits), 8):
+            v = int(bits[i:i + 8], 2)
+            out.append(v)
+            if v == 0xFF:
+                out.append(0)
+        return out
+
+    lone16, lone15 = [0] * 15 + [1], [0] * 14 + [1, 0]
+    g8 = encode(picture(8, 8, 3, gray=True), quality=75)
+    std_ac = seg_of(g8, 0xC4, 1)                  # Pillow's (= Annex K's) AC luminance table: "1010" is end-of-block
+    assert g8[std_ac[1] + 4] == 0x10
+    std_ac_counts, std_ac_bytes = g8[std_ac[1] + 5:std_ac[1] + 21], g8[std_ac[1] + 21:std_ac[2]]
+    # DC: lone 16-bit code 0...0 = category 2; blocks: DC code + 2 value bits + AC end-of-block "1010"
+    add("deep_dc16.jpg", tiny_gray(lone16, [2], std_ac_counts, std_ac_bytes,
+                                   bits_to_bytes("".join("0" * 16 + v + "1010" for v in ("11", "00", "10", "01")))),
+        "DC table with one 16-bit code: 131071-node tree")
+    # both tables deep; AC symbol 0x11 (run 1, size 1) then the other blocks use codes that land on symbol-less leaves (symbol 0)
+    add("deep_dc16_ac15.jpg", tiny_gray(lone16, [1], lone15, [0x00],
+                                        bits_to_bytes("".join("0" * 16 + v + "0" * 15 for v in "1010"))),
+        "lone 16-bit DC code and lone 15-bit AC code")
+    # codes that end on leaves the build never gave a symbol (calloc'd: symbol 0): 14 zeros then a one
+    add("deep_dc16_unassigned.jpg", tiny_gray(lone16, [3], lone15, [0x00],
+                                              bits_to_bytes("".join("0" * 14 + "10" + "0" * 13 + "10" for _ in range(4)))),
+        "codes of a deep table that reach symbol-less leaves")
     # random single-bit damage inside the entropy-coded data
     rng = np.random.default_rng(7)
     for tag, d, first in (("base", base, ss[2]), ("prog", prog, sos[0] + 14)):

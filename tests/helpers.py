@@ -48,7 +48,7 @@ def synth_planes(d, seed, kind=0):
     return [pyoracle.synth_blocks(plane_shape(d, c)[0], seed + c, 0, kind) for c in range(d.nbcomp)]
 
 
-def fnv1a64(a):
-    """FNV-1a over 8-byte words (vectorised xor-fold variant is NOT FNV; keep it simple and exact)."""
+def sha256_hex(a):
+    """SHA-256 of an array's bytes (the digest the golden metadata stores)."""
     import hashlib
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()

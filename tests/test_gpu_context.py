@@ -1,0 +1,135 @@
+"""GPU suite: per-device contexts (jpeggpu_ctx_*), the threading contract, and the pipelined host-pointer form
+(stripes over two streams; pinned caller memory moved in place, pageable memory staged).  Bit-exact vs the oracle."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import helpers
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+orc = pyoracle.oracle
+QT = helpers.qtables_ramp()
+
+
+def _frame(w, h, samp, seed, kind=0):
+    d = helpers.oracle_desc(w, h, samp)
+    planes = helpers.synth_planes(d, seed, kind)
+    return d, planes, orc.backend_run(d, planes, QT)
+
+
+def test_two_contexts_from_two_threads(gpu):
+    """Two contexts on device 0, each driven by its own thread (the shape of 'one host thread per GPU'), many frames
+    each, host-pointer and device-pointer forms: every raster equals the oracle's."""
+    import torch
+    cases = [_frame(333, 70, ((2, 2), (1, 1), (1, 1)), 21), _frame(500, 41, ((1, 1),) * 3, 22)]
+    errors = []
+
+    def worker(idx):
+        try:
+            d, planes, want = cases[idx]
+            gd = helpers.to_gpu_desc(gpu, d)
+            with gpu.Context(0) as ctx:
+                assert ctx.device == 0
+                for _ in range(12):
+                    got = gpu.backend_run(gd, planes, QT, ctx=ctx)
+                    assert np.array_equal(got, want)
+                dev = [torch.from_numpy(p).cuda() for p in planes]
+                out = torch.zeros(want.size, dtype=torch.uint8, device="cuda")
+                torch.cuda.synchronize()
+                for _ in range(12):
+                    gpu.backend_run_device(gd, [t.data_ptr() for t in dev], QT, out.data_ptr(), ctx=ctx)
+                ctx.synchronize()
+                assert np.array_equal(out.cpu().numpy().reshape(want.shape), want)
+        except BaseException as e:   # noqa: BLE001  (reported by the main thread)
+            errors.append((idx, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
+
+
+def test_process_wide_entry_from_a_second_thread(gpu):
+    """HIP's current device is per thread: an entry point called from a thread that never called jpeggpu_init binds
+    itself to the context's device."""
+    d, planes, want = _frame(129, 33, ((2, 1), (1, 1), (1, 1)), 23)
+    res = {}
+
+    def worker():
+        try:
+            res["got"] = gpu.backend_run(helpers.to_gpu_desc(gpu, d), planes, QT)
+            res["idct"] = gpu.idct_opt_blocks(np.zeros((3, 8, 8), np.int16))
+        except BaseException as e:   # noqa: BLE001
+            res["err"] = repr(e)
+
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join()
+    assert "err" not in res, res
+    assert np.array_equal(res["got"], want) and np.all(res["idct"] == 128)
+
+
+def test_context_option_is_per_context(gpu):
+    """idct_fast is part of the context: a '-f' context and a default one side by side."""
+    d = helpers.oracle_desc(64, 16, ((1, 1),))
+    planes = helpers.synth_planes(d, 24)
+    gd = helpers.to_gpu_desc(gpu, d)
+    fast = orc.backend_run(d, planes, QT)
+    orc.set_idct_fast(False)
+    try:
+        slow = orc.backend_run(d, planes, QT)
+    finally:
+        orc.set_idct_fast(True)
+    with gpu.Context(0) as a, gpu.Context(0) as b:
+        b.set_idct_fast(False)
+        assert a.get_idct_fast() and not b.get_idct_fast() and gpu.get_idct_fast()
+        ra = gpu.backend_run(gd, planes, QT, ctx=a)
+        rb = gpu.backend_run(gd, planes, QT, ctx=b)
+        assert np.array_equal(ra, fast)
+        assert np.array_equal(rb, slow)
+        assert np.max(np.abs(ra.astype(int) - rb.astype(int))) <= 1    # test/idct_opt_test.c:35
+        assert np.array_equal(gpu.backend_run(gd, planes, QT), fast)  # the default context is untouched
+
+
+def test_ctx_errors(gpu):
+    with pytest.raises(gpu.JpegGpuError) as e:
+        gpu.Context(9999)
+    assert e.value.code == gpu.ERR_NO_DEVICE
+
+
+@pytest.mark.parametrize("stripe", [1, 200000, 0], ids=["one_row_stripes", "200kB_stripes", "default"])
+@pytest.mark.parametrize("pinned", [False, True], ids=["pageable", "registered"])
+def test_host_pointer_pipeline(gpu, stripe, pinned):
+    """jpeggpu_backend_run with many / few / one stripe, caller memory pageable (staged) or registered (DMA in place),
+    packed and padded output rows."""
+    old = os.environ.get("JPEGGPU_STRIPE_BYTES")
+    if stripe:
+        os.environ["JPEGGPU_STRIPE_BYTES"] = str(stripe)
+    gpu.reload_tuning()
+    try:
+        for samp, (w, h) in ((((2, 2), (1, 1), (1, 1)), (1000, 333)), (((1, 1),) * 3, (517, 130)), (((1, 1),), (2049, 97))):
+            d, planes, want = _frame(w, h, samp, 31)
+            gd = helpers.to_gpu_desc(gpu, d)
+            rb = want.shape[1]
+            for stride in (0, rb + 37):
+                buf = np.full((want.shape[0], stride or rb), 0xCD, dtype=np.uint8)
+                if pinned:
+                    [gpu.host_register(p) for p in planes]
+                    gpu.host_register(buf)
+                try:
+                    got = gpu.backend_run(gd, planes, QT, out=buf, out_stride=stride)
+                finally:
+                    if pinned:
+                        [gpu.host_unregister(p) for p in planes]
+                        gpu.host_unregister(buf)
+                assert np.array_equal(got[:, :rb], want), (samp, w, h, stride)
+                assert np.all(buf[:, rb:] == 0xCD)
+    finally:
+        if old is None:
+            os.environ.pop("JPEGGPU_STRIPE_BYTES", None)
+        else:
+            os.environ["JPEGGPU_STRIPE_BYTES"] = old
+        gpu.reload_tuning()

@@ -136,6 +136,7 @@ def test_other_tilings_and_prologues(gpu, env):
     two wide (generic pixel phase) stay bit-exact: the tuning knobs select them."""
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
+    gpu.reload_tuning()          # the knobs are read from the environment once, not per launch
     try:
         for samp in (((1, 1),) * 3, ((2, 2), (1, 1), (1, 1)), ((2, 1), (1, 1), (1, 1)), ((1, 1),)):
             d = helpers.oracle_desc(1500 + 8 * len(samp), 70, samp)
@@ -147,6 +148,7 @@ def test_other_tilings_and_prologues(gpu, env):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        gpu.reload_tuning()
 
 
 def test_full_int16_range_and_wrap(gpu):
