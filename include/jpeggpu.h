@@ -184,13 +184,18 @@ int jpeggpu_ctx_backend_run_batch_device(jpeggpu_ctx_t *ctx, const jpeggpu_frame
                                          void *hip_stream);
 int jpeggpu_ctx_synchronize(jpeggpu_ctx_t *ctx, void *hip_stream);
 
-/* Pins caller memory in place (hipHostRegister).  jpeggpu_backend_run moves planes and rasters that are
- * pinned -- by this call, by hipHostRegister or by hipHostMalloc -- with the DMA engines directly; pageable
- * memory (what the reference's calloc gives, src/progressive.c:73-84) goes through pinned stripe buffers.
- * Register once per buffer, not per call: pinning costs about as much as copying.  No counterpart in
- * the reference.                                                                                        */
-int jpeggpu_host_register(void *ptr, size_t bytes);
-int jpeggpu_host_unregister(void *ptr);
+/* Pinned host memory.  jpeggpu_backend_run moves planes and rasters that are pinned -- allocated by
+ * jpeggpu_host_alloc / hipHostMalloc, or registered in place by jpeggpu_host_register / hipHostRegister --
+ * with the DMA engines directly; pageable memory (what the reference's calloc gives,
+ * src/progressive.c:73-84) goes through pinned stripe buffers, one extra copy each way.  A binding that
+ * lays `sortie` out contiguously allocates it with jpeggpu_host_alloc instead of calloc.
+ * In-place registration needs driver support for user pointers (it is refused with JPEGGPU_ERR_HIP on
+ * hosts without it) and costs about as much as a copy: register once per buffer, not per call.
+ * No counterpart in the reference.                                                                      */
+void *jpeggpu_host_alloc(size_t bytes);          /* NULL on failure (jpeggpu_last_error() says why); not zeroed */
+void  jpeggpu_host_free(void *ptr);
+int   jpeggpu_host_register(void *ptr, size_t bytes);
+int   jpeggpu_host_unregister(void *ptr);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Stage-level array forms of the four function contracts (host pointers, synchronous).        */

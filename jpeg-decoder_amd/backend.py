@@ -98,6 +98,10 @@ lib.jpeggpu_ctx_backend_run.argtypes = [_vp] + lib.jpeggpu_backend_run.argtypes
 lib.jpeggpu_ctx_backend_run_device.argtypes = [_vp] + lib.jpeggpu_backend_run_device.argtypes
 lib.jpeggpu_ctx_backend_run_batch_device.argtypes = [_vp] + lib.jpeggpu_backend_run_batch_device.argtypes
 lib.jpeggpu_ctx_synchronize.argtypes = [_vp, _vp]
+lib.jpeggpu_host_alloc.argtypes = [_sz]
+lib.jpeggpu_host_alloc.restype = _vp
+lib.jpeggpu_host_free.argtypes = [_vp]
+lib.jpeggpu_host_free.restype = None
 lib.jpeggpu_host_register.argtypes = [_vp, _sz]
 lib.jpeggpu_host_unregister.argtypes = [_vp]
 lib.jpeggpu_internal_reload_tuning.restype = None
@@ -167,6 +171,24 @@ def reload_tuning():
     """The JPEGGPU_* tuning knobs are read from the environment once; tests and tools that change them inside one
     process ask for them to be read again."""
     lib.jpeggpu_internal_reload_tuning()
+
+
+class PinnedArray:
+    """A numpy view of jpeggpu_host_alloc memory (pinned: jpeggpu_backend_run moves it by DMA in place)."""
+
+    def __init__(self, shape, dtype):
+        self.array = None
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self.ptr = lib.jpeggpu_host_alloc(n)
+        if not self.ptr:
+            raise JpegGpuError(ERR_HIP, last_error())
+        self.array = np.frombuffer((C.c_uint8 * n).from_address(self.ptr), dtype=dtype).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            lib.jpeggpu_host_free(self.ptr)
+            self.ptr = None
 
 
 def host_register(arr):

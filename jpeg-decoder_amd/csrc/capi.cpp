@@ -51,7 +51,10 @@ int fail(int code, const char *fmt, ...) {
 #define HIP_TRY(expr)                                                                            \
    do {                                                                                          \
       hipError_t e_ = (expr);                                                                    \
-      if (e_ != hipSuccess) return fail(JPEGGPU_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+      if (e_ != hipSuccess) {                                                                    \
+         (void)hipGetLastError();   /* reported here: must not resurface from a later launch's hipGetLastError() */ \
+         return fail(JPEGGPU_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));                    \
+      }                                                                                          \
    } while (0)
 
 // ---- tuning knobs: read from the environment ONCE (first use), never per launch --------------------
@@ -529,7 +532,17 @@ int jpeggpu_backend_run(const jpeggpu_frame_desc_t *d, const jpeggpu_blocl16_t *
    return run_host(c, d, coef, qt, out, out_stride);
 }
 
-// Pins caller memory in place so that jpeggpu_backend_run reads / writes it by DMA (no staging copy).
+// Pinned host memory for planes and rasters: jpeggpu_backend_run moves it by DMA in place (no staging copy).
+void *jpeggpu_host_alloc(size_t bytes) {
+   jpeggpu_ctx_s *c; if (default_ctx(&c)) return nullptr;
+   void *p = nullptr;
+   hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+   if (e != hipSuccess) { fail(JPEGGPU_ERR_HIP, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); return nullptr; }
+   return p;
+}
+void jpeggpu_host_free(void *ptr) { if (ptr) (void)hipHostFree(ptr); }
+
+// Pins caller memory in place (where the driver supports it) to the same effect.
 int jpeggpu_host_register(void *ptr, size_t bytes) {
    if (!ptr || !bytes) return fail(JPEGGPU_ERR_INVALID_ARG, "NULL argument");
    jpeggpu_ctx_s *c; int rc = default_ctx(&c); if (rc) return rc;

@@ -470,6 +470,7 @@ hipError_t launch_backend(const BackendParams &p, const LaunchDims &d, hipStream
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d.lds_bytes);
       if (e != hipSuccess) return e;
    }
+   (void)hipGetLastError();   // a stale error of this thread (any earlier HIP call, ours or the caller's) is not this launch's
    hipLaunchKernelGGL(k, grid, block, d.lds_bytes, s, p);
    return hipGetLastError();
 }
@@ -558,26 +559,31 @@ static inline unsigned nblocks(size_t work, unsigned per) { return (unsigned)((w
 hipError_t launch_iquant(void *d_blocks, size_t n, int s_start, int s_end, const uint32_t qt_packed[32], hipStream_t s) {
    if (n == 0) return hipSuccess;
    QtArg q; for (int i = 0; i < 32; i++) q.w[i] = qt_packed[i];
+   (void)hipGetLastError();
    hipLaunchKernelGGL(iquant_kernel, dim3(nblocks(n * 64, 256)), dim3(256), 0, s, static_cast<int16_t *>(d_blocks), n, s_start, s_end, q);
    return hipGetLastError();
 }
 hipError_t launch_izz(const void *d_in, void *d_out, size_t n, hipStream_t s) {
    if (n == 0) return hipSuccess;
+   (void)hipGetLastError();
    hipLaunchKernelGGL(izz_kernel, dim3(nblocks(n * 64, 256)), dim3(256), 0, s, static_cast<const int16_t *>(d_in), static_cast<int16_t *>(d_out), n);
    return hipGetLastError();
 }
 hipError_t launch_idct(const void *d_in, void *d_out, size_t n, hipStream_t s) {
    if (n == 0) return hipSuccess;
+   (void)hipGetLastError();
    hipLaunchKernelGGL(idct_kernel, dim3(nblocks(n, 64)), dim3(64), 0, s, static_cast<const int16_t *>(d_in), static_cast<uint8_t *>(d_out), n);
    return hipGetLastError();
 }
 hipError_t launch_idct_slow(const void *d_in, void *d_out, size_t n, const float *d_coef, hipStream_t s) {
    if (n == 0) return hipSuccess;
+   (void)hipGetLastError();
    hipLaunchKernelGGL(idct_slow_kernel, dim3(nblocks(n, 64)), dim3(64), 0, s, static_cast<const int16_t *>(d_in), static_cast<uint8_t *>(d_out), n, d_coef);
    return hipGetLastError();
 }
 hipError_t launch_ycc2rgb(const uint8_t *d_y, const uint8_t *d_cb, const uint8_t *d_cr, uint8_t *d_rgb, size_t n, hipStream_t s) {
    if (n == 0) return hipSuccess;
+   (void)hipGetLastError();
    hipLaunchKernelGGL(ycc2rgb_kernel, dim3(nblocks((n + 3) / 4, 256)), dim3(256), 0, s, d_y, d_cb, d_cr, d_rgb, n);
    return hipGetLastError();
 }

@@ -20,6 +20,15 @@ def _frame(w, h, samp, seed, kind=0):
     return d, planes, orc.backend_run(d, planes, QT)
 
 
+def _page_aligned(a):
+    """A copy of `a` on pages of its own (hipHostRegister pins whole pages; two buffers must not share one)."""
+    raw = np.empty(a.nbytes + 2 * 4096, dtype=np.uint8)
+    o = (-raw.ctypes.data) % 4096
+    v = raw[o:o + a.nbytes].view(a.dtype).reshape(a.shape)
+    v[...] = a
+    return v
+
+
 def test_two_contexts_from_two_threads(gpu):
     """Two contexts on device 0, each driven by its own thread (the shape of 'one host thread per GPU'), many frames
     each, host-pointer and device-pointer forms: every raster equals the oracle's."""
@@ -101,7 +110,7 @@ def test_ctx_errors(gpu):
 
 
 @pytest.mark.parametrize("stripe", [1, 200000, 0], ids=["one_row_stripes", "200kB_stripes", "default"])
-@pytest.mark.parametrize("pinned", [False, True], ids=["pageable", "registered"])
+@pytest.mark.parametrize("pinned", [None, "alloc", "register"], ids=["pageable", "host_alloc", "registered"])
 def test_host_pointer_pipeline(gpu, stripe, pinned):
     """jpeggpu_backend_run with many / few / one stripe, caller memory pageable (staged) or registered (DMA in place),
     packed and padded output rows."""
@@ -116,17 +125,31 @@ def test_host_pointer_pipeline(gpu, stripe, pinned):
             rb = want.shape[1]
             for stride in (0, rb + 37):
                 buf = np.full((want.shape[0], stride or rb), 0xCD, dtype=np.uint8)
-                if pinned:
-                    [gpu.host_register(p) for p in planes]
-                    gpu.host_register(buf)
+                src, held = planes, []
+                if pinned == "alloc":
+                    held = [gpu.PinnedArray(p.shape, p.dtype) for p in planes] + [gpu.PinnedArray(buf.shape, buf.dtype)]
+                    for hp, p in zip(held, planes + [buf]):
+                        hp.array[...] = p
+                    src, buf = [hp.array for hp in held[:-1]], held[-1].array
+                elif pinned == "register":
+                    src, buf = [_page_aligned(p) for p in planes], _page_aligned(buf)
+                    try:
+                        gpu.host_register(buf)
+                    except gpu.JpegGpuError as e:
+                        assert e.code == gpu.ERR_HIP
+                        pytest.skip("this host's driver does not pin user pointers (hipHostRegister refused)")
+                    [gpu.host_register(p) for p in src]
                 try:
-                    got = gpu.backend_run(gd, planes, QT, out=buf, out_stride=stride)
+                    got = gpu.backend_run(gd, src, QT, out=buf, out_stride=stride).copy()
+                    pad = buf[:, rb:].copy()
                 finally:
-                    if pinned:
-                        [gpu.host_unregister(p) for p in planes]
+                    if pinned == "register":
+                        [gpu.host_unregister(p) for p in src]
                         gpu.host_unregister(buf)
+                    del src, buf
+                    [hp.free() for hp in held]
                 assert np.array_equal(got[:, :rb], want), (samp, w, h, stride)
-                assert np.all(buf[:, rb:] == 0xCD)
+                assert np.all(pad == 0xCD)
     finally:
         if old is None:
             os.environ.pop("JPEGGPU_STRIPE_BYTES", None)
