@@ -184,6 +184,23 @@ int jpeggpu_ctx_backend_run_batch_device(jpeggpu_ctx_t *ctx, const jpeggpu_frame
                                          void *hip_stream);
 int jpeggpu_ctx_synchronize(jpeggpu_ctx_t *ctx, void *hip_stream);
 
+/* Allocation-free variant of jpeggpu_backend_run (host pointers in and out, synchronous, same bytes).
+ * NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot allocate device memory -- code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc.  Nothing on its path calls hipMalloc,
+ * hipFree, hipHostMalloc or any other allocating routine: the device staging that jpeggpu_backend_run grows on
+ * demand (coefficient planes in, packed raster out) is a 32 MiB array held statically in the library's device
+ * image, one copy on every GPU the library runs on, for the life of the process.
+ *   ctx   : a context from jpeggpu_ctx_create, or NULL for the default context, which must already exist
+ *           (jpeggpu_init; creating a context allocates, so it is not done here).
+ *   limit : sum of the planes (each rounded up to 256 bytes) + rows * row_bytes <= 32 MiB, e.g. one
+ *           1920x1080 frame in any sampling; larger frames return JPEGGPU_ERR_INVALID_ARG and touch nothing.
+ *   With idct_fast == 0 the context must already hold the "-f" table (one ordinary call in that mode).
+ * All calls on one GPU of a process share that GPU's array: the library serialises them, each call overwrites
+ * what the last one left there, and nothing else may use the array while a call runs.                        */
+int jpeggpu_backend_run_noalloc(jpeggpu_ctx_t *ctx, const jpeggpu_frame_desc_t *desc,
+                                const jpeggpu_blocl16_t *const coef[3], const jpeggpu_qtable_t *const qtables[4],
+                                uint8_t *out, size_t out_stride);
+
 /* Pinned host memory.  jpeggpu_backend_run moves planes and rasters that are pinned -- allocated by
  * jpeggpu_host_alloc / hipHostMalloc, or registered in place by jpeggpu_host_register / hipHostRegister --
  * with the DMA engines directly; pageable memory (what the reference's calloc gives,

@@ -34,6 +34,7 @@ struct jpeggpu_ctx_s {
    std::atomic<int> idct_fast{ 1 };              // all_option.idct_fast of this context
    std::mutex slow_mu;
    std::atomic<float *> d_slow_coef{ nullptr };  // calc_coef's table on the device, built on first use
+   void *static_scratch = nullptr;               // device address of kernels.hip's static staging array on this device
 };
 
 namespace {
@@ -86,6 +87,8 @@ std::mutex g_mu;                        // creation / destruction of the default
 std::atomic<jpeggpu_ctx_s *> g_default{ nullptr };
 std::atomic<int> g_idct_fast{ 1 };      // the process-wide option (jpeggpu_set_idct_fast); survives jpeggpu_shutdown
 
+void ctx_delete(jpeggpu_ctx_s *c);
+
 int ctx_new(int device, jpeggpu_ctx_s **out) {
    int n = 0;
    hipError_t e = hipGetDeviceCount(&n);
@@ -106,6 +109,12 @@ int ctx_new(int device, jpeggpu_ctx_s **out) {
       return fail(JPEGGPU_ERR_HIP, "stream/event creation on device %d: %s", device, hipGetErrorString(rc));
    }
    c->idct_fast.store(g_idct_fast.load());
+   // jpeggpu_backend_run_noalloc: the address of the static staging array on THIS device, looked up here, at set-up
+   hipError_t se = static_scratch(device, &c->static_scratch);
+   if (se != hipSuccess) {
+      ctx_delete(c);
+      return fail(JPEGGPU_ERR_HIP, "hipGetSymbolAddress(scratch) on device %d: %s", device, hipGetErrorString(se));
+   }
    *out = c;
    return 0;
 }
@@ -277,7 +286,8 @@ void plan_backend(const jpeggpu_frame_desc_t *d, const jpeggpu_qtable_t *const q
 }
 
 int run_device(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, uint32_t nframes, const void *const d_coef[3], const size_t cfs[3],
-               const jpeggpu_qtable_t *const qt[4], void *d_out, size_t out_stride, size_t out_frame_stride, hipStream_t s) {
+               const jpeggpu_qtable_t *const qt[4], void *d_out, size_t out_stride, size_t out_frame_stride, hipStream_t s,
+               bool may_alloc = true) {
    BackendParams p; LaunchDims ld;
    plan_backend(d, qt, p, ld);
    const size_t row_bytes = jpeggpu_raster_row_bytes(d), rows = jpeggpu_raster_rows(d);
@@ -299,7 +309,11 @@ int run_device(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, uint32_t nfram
    if (const char *e = getenv("JPEGGPU_DIAG_PTR")) p.diag = (void *)strtoull(e, nullptr, 0);
 #endif
    if (nframes == 0) return 0;
-   if (!ctx->idct_fast.load()) { int rc = ensure_slow_coef(ctx, &p.slow_coef); if (rc) return rc; }   // the option is read ONCE per call
+   if (!ctx->idct_fast.load()) {   // the option is read ONCE per call
+      if (!may_alloc && !ctx->d_slow_coef.load())
+         return fail(JPEGGPU_ERR_INVALID_ARG, "idct_fast == 0 needs its coefficient table on the device: make one ordinary call in this mode first");
+      int rc = ensure_slow_coef(ctx, &p.slow_coef); if (rc) return rc;
+   }
    if (nframes > 65535 || d->nbmcuV > 65535) return fail(JPEGGPU_ERR_INVALID_ARG, "nframes / nbmcuV above 65535");
    ld.frames = nframes;
    HIP_TRY(launch_backend(p, ld, s));
@@ -530,6 +544,45 @@ int jpeggpu_backend_run(const jpeggpu_frame_desc_t *d, const jpeggpu_blocl16_t *
    for (int c = 0; c < d->nbcomp; c++) if (!coef || !coef[c]) return fail(JPEGGPU_ERR_INVALID_ARG, "coef[%d] is NULL", c);
    jpeggpu_ctx_s *c; rc = default_ctx(&c); if (rc) return rc;
    return run_host(c, d, coef, qt, out, out_stride);
+}
+
+// The allocation-free variant of jpeggpu_backend_run: same bytes, no hipMalloc / hipFree / hipHostMalloc anywhere on
+// its path.  The device staging (planes in, packed raster out) is kernels.hip's static array; its address on this
+// device was looked up when the context was created.  Nothing in the array has to start at zero: the planes are
+// overwritten by the upload before the kernel reads them and the kernel writes every byte of the packed raster.
+// All calls on one GPU of this process share the array, so they are serialised here; the previous call's bytes stay
+// in it until overwritten.
+int jpeggpu_backend_run_noalloc(jpeggpu_ctx_t *ctx, const jpeggpu_frame_desc_t *d, const jpeggpu_blocl16_t *const coef[3],
+                                const jpeggpu_qtable_t *const qt[4], uint8_t *out, size_t out_stride) {
+   static std::mutex device_mu[kMaxDevices];
+   int rc = validate(d, qt); if (rc) return rc;
+   if (!out) return fail(JPEGGPU_ERR_INVALID_ARG, "out is NULL");
+   for (int c = 0; c < d->nbcomp; c++) if (!coef || !coef[c]) return fail(JPEGGPU_ERR_INVALID_ARG, "coef[%d] is NULL", c);
+   if (!ctx) ctx = g_default.load();
+   if (!ctx) return fail(JPEGGPU_ERR_INVALID_ARG, "no context: jpeggpu_init() / jpeggpu_ctx_create() first (creating one allocates)");
+   rc = bind(ctx); if (rc) return rc;
+   const size_t row_bytes = jpeggpu_raster_row_bytes(d), rows = jpeggpu_raster_rows(d), out_bytes = row_bytes * rows;
+   if (out_stride == 0) out_stride = row_bytes;
+   if (out_stride < row_bytes) return fail(JPEGGPU_ERR_INVALID_ARG, "out_stride %zu < row bytes %zu", out_stride, row_bytes);
+   size_t off[3] = { 0, 0, 0 }, in_bytes = 0;
+   for (int c = 0; c < d->nbcomp; c++) { off[c] = in_bytes; in_bytes += (jpeggpu_plane_blocks(d, c) * sizeof(jpeggpu_blocl16_t) + 255) & ~(size_t)255; }
+   if (in_bytes + out_bytes > kStaticScratchBytes)
+      return fail(JPEGGPU_ERR_INVALID_ARG, "frame needs %zu bytes of device staging (planes %zu + raster %zu); the static buffer of jpeggpu_backend_run_noalloc holds %zu",
+                  in_bytes + out_bytes, in_bytes, out_bytes, (size_t)kStaticScratchBytes);
+   uint8_t *base = (uint8_t *)ctx->static_scratch;     // the DEVICE address, never the array's name
+   std::lock_guard<std::mutex> lk(device_mu[ctx->device]);
+   const void *dc[3] = { nullptr, nullptr, nullptr };
+   for (int c = 0; c < d->nbcomp; c++) {
+      HIP_TRY(hipMemcpyAsync(base + off[c], coef[c], jpeggpu_plane_blocks(d, c) * sizeof(jpeggpu_blocl16_t), hipMemcpyHostToDevice, ctx->stream));
+      dc[c] = base + off[c];
+   }
+   uint8_t *d_raster = base + in_bytes;
+   rc = run_device(ctx, d, 1, dc, nullptr, qt, d_raster, row_bytes, 0, ctx->stream, false);
+   if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+   if (out_stride == row_bytes) HIP_TRY(hipMemcpyAsync(out, d_raster, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+   else HIP_TRY(hipMemcpy2DAsync(out, out_stride, d_raster, row_bytes, row_bytes, rows, hipMemcpyDeviceToHost, ctx->stream));
+   HIP_TRY(hipStreamSynchronize(ctx->stream));
+   return 0;
 }
 
 // Pinned host memory for planes and rasters: jpeggpu_backend_run moves it by DMA in place (no staging copy).

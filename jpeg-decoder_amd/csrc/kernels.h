@@ -44,6 +44,12 @@ struct LaunchDims { uint32_t tiles_per_row, mcu_rows, frames, threads; size_t ld
 
 hipError_t launch_backend(const BackendParams &p, const LaunchDims &d, hipStream_t s);
 
+// Device staging of jpeggpu_backend_run_noalloc: a file-scope __device__ array in kernels.hip (one copy per GPU).
+// static_scratch() returns ITS DEVICE ADDRESS on <device> (hipGetSymbolAddress, once per device, cached).
+constexpr size_t kStaticScratchBytes = (size_t)32 << 20;
+constexpr int kMaxDevices = 64;
+hipError_t static_scratch(int device, void **ptr);
+
 // stage-level kernels (device pointers)
 hipError_t launch_iquant(void *d_blocks, size_t n, int s_start, int s_end, const uint32_t qt_packed[32], hipStream_t s);
 hipError_t launch_izz(const void *d_in, void *d_out, size_t n, hipStream_t s);

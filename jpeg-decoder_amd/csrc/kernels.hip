@@ -14,6 +14,7 @@
 //
 // Compiled with -ffp-contract=off (see jpeg_math.hpp).
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include "jpeg_math.hpp"
 #include "kernels.h"
 
@@ -473,6 +474,33 @@ hipError_t launch_backend(const BackendParams &p, const LaunchDims &d, hipStream
    (void)hipGetLastError();   // a stale error of this thread (any earlier HIP call, ours or the caller's) is not this launch's
    hipLaunchKernelGGL(k, grid, block, d.lds_bytes, s, p);
    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Statically allocated device staging for the allocation-free entry point (jpeggpu_backend_run_noalloc):
+// coefficient planes in, raster out, for callers that may not call hipMalloc.  Every GPU the library runs on
+// holds its own copy of this array, at its own address, until the process ends.  In host code the NAME `scratch`
+// is only a handle for hipGetSymbolAddress: the device address is looked up once per device (with that device
+// current) and everything -- copies, kernel arguments -- uses that pointer.
+// ------------------------------------------------------------------------------------------
+static __device__ __align__(256) uint8_t scratch[kStaticScratchBytes];
+
+hipError_t static_scratch(int device, void **ptr) {
+   static std::mutex mu;
+   static void *addr[kMaxDevices] = {};
+   if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+   std::lock_guard<std::mutex> lk(mu);
+   if (!addr[device]) {
+      hipError_t e = hipSetDevice(device);
+      if (e != hipSuccess) return e;
+      void *p = nullptr;
+      e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+      if (e != hipSuccess) return e;
+      if (!p) return hipErrorInvalidSymbol;
+      addr[device] = p;
+   }
+   *ptr = addr[device];
+   return hipSuccess;
 }
 
 // ------------------------------------------------------------------------------------------
