@@ -104,7 +104,9 @@ __device__ __forceinline__ void pixel_phase(const BackendParams &p, const uint8_
                   (size_t)m * p.tile_rows * p.out_stride;
    const uint32_t pitch0 = p.bw[0] * 8;
    if (p.nbcomp == 1) {
-      // save_mcu_ligne_bw (src/decoder_utils.c:48-63): straight copy of the luma plane
+      // save_mcu_ligne_bw (src/decoder_utils.c:48-63): straight copy of the luma plane.  The reference reads block
+      // x/8 of the MCU row's FIRST block row with py = y % 8 (:55-58): when the single component has vsampling > 1
+      // the rows 8.. of the band repeat rows 0..7 -- hence the "& 7" on the source row (a no-op for 1x1 sampling)
 #if !defined(JM_GRAY_QUADS)
       if (p.wq_shift != 0xFFFFFFFFu && wq >= 4) {
          // power-of-two tile: 16 pixels per item, the item index is the plane's 16-byte word index
@@ -117,7 +119,7 @@ __device__ __forceinline__ void pixel_phase(const BackendParams &p, const uint8_
             const uint32_t yi = it >> ws, x = (it & ((wq >> 2) - 1)) * 16;
             if (x >= rem) continue;
             const uint32_t left = rem - x;
-            const uint4 v = *reinterpret_cast<const uint4 *>(lds + p.plane_off[0] + it * 16);
+            const uint4 v = *reinterpret_cast<const uint4 *>(lds + p.plane_off[0] + (((yi & 7) << ws) | (it & ((wq >> 2) - 1))) * 16);
             uint8_t *dst = tile_out + (yi * stride + x);
             if (left >= 16) {
                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -138,7 +140,7 @@ __device__ __forceinline__ void pixel_phase(const BackendParams &p, const uint8_
          if (ix >= wq) { ix -= wq; iy++; }
          if (x0 + x >= p.width) continue;
          uint32_t n = min(4u, p.width - (x0 + x));
-         uint32_t v = *reinterpret_cast<const uint32_t *>(lds + p.plane_off[0] + y * pitch0 + x);
+         uint32_t v = *reinterpret_cast<const uint32_t *>(lds + p.plane_off[0] + (y & 7) * pitch0 + x);
          uint8_t *dst = out + (size_t)y * p.out_stride + x0 + x;
          if (n == 4 && ((uintptr_t)dst & 3) == 0) *reinterpret_cast<uint32_t *>(dst) = v;
          else for (uint32_t i = 0; i < n; i++) dst[i] = (uint8_t)(v >> (8 * i));

@@ -123,7 +123,15 @@ int main(int argc, char **argv) {
    { int one[3] = { 1, 1, 1 };
      check_frame(8, 8, 1, one, one, 1, 7, 0, qt);
      check_frame(61, 37, 1, one, one, 1, 8, 2, qt);
-     check_frame(300, 225, 1, one, one, 0, 9, 0, qt); }
+     check_frame(300, 225, 1, one, one, 0, 9, 0, qt);
+     /* gray with sampling factors above 1: save_mcu_ligne_bw only ever reads the first block row of an MCU row
+        (src/decoder_utils.c:55-58), so rows 8.. of each band repeat rows 0..7 */
+     int g22h[3] = { 2, 1, 1 }, g22v[3] = { 2, 1, 1 }, g12v[3] = { 2, 1, 1 }, g41h[3] = { 4, 1, 1 }, g14v[3] = { 4, 1, 1 };
+     check_frame(61, 37, 1, g22h, g22v, 1, 10, 0, qt);
+     check_frame(130, 70, 1, one, g12v, 1, 11, 1, qt);
+     check_frame(97, 20, 1, g41h, one, 0, 12, 0, qt);
+     check_frame(40, 90, 1, one, g14v, 1, 13, 0, qt);
+     check_frame(200, 64, 1, g41h, g14v, 1, 14, 2, qt); }
 
    printf(fails ? "check_oracle_vs_ref: %d FAILURES\n" : "check_oracle_vs_ref: ALL IDENTICAL (%d failures)\n", fails);
    return fails != 0;

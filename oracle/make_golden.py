@@ -76,6 +76,22 @@ for name, samp in combos.items():
             small[key] = out
 np.savez_compressed(os.path.join(OUT, "frame_vectors_small.npz"), **small)
 
+# ---- BASELINE.json sizes: SHA-256 of the WHOLE raster the reference objects produce ----------------------
+# (same frames as tests/test_gpu_parity.py::test_baseline_sizes builds: seed 0x5EED0000 + len(name))
+big = {"c2_4096x4096_444": (4096, 4096, ((1, 1),) * 3), "c3_8192x8192_420": (8192, 8192, ((2, 2), (1, 1), (1, 1))),
+       "c4_4096x4096_422": (4096, 4096, ((2, 1), (1, 1), (1, 1))), "c1_512x512_gray": (512, 512, ((1, 1),)),
+       "c5_1920x1080_420": (1920, 1080, ((2, 2), (1, 1), (1, 1)))}
+meta["baseline_sizes"] = {}
+for name, (w, h, samp) in sorted(big.items()):
+    d = helpers.oracle_desc(w, h, samp)
+    planes = helpers.synth_planes(d, 0x5EED0000 + len(name))
+    out = ref.backend_run(d, planes, qt)
+    band = d.max_v * 8
+    meta["baseline_sizes"][name] = {"width": w, "height": h, "sampling": samp, "seed": 0x5EED0000 + len(name), "rows": int(out.shape[0]),
+                                    "sha256": sha(out), "sha256_first_band": sha(out[:band]), "sha256_last_band": sha(out[-band:])}
+    print("baseline size", name, out.shape, meta["baseline_sizes"][name]["sha256"][:16])
+    del out, planes
+
 # ---- the reference's own end-to-end goldens --------------------------------------------------
 ref.lib.ref_dump_baseline_planes.argtypes = [C.c_char_p, C.POINTER(pyoracle.FrameDesc), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]
 for jpg, gold in (("invader_normal.jpeg", "invader.pgm"), ("shaun_the_sheep.jpeg", "shaun_the_sheep.ppm")):

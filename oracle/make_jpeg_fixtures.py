@@ -158,6 +158,15 @@ def main():
     add("base_444_comment_24x24.jpeg", encode(picture(24, 24, 92), quality=70, subsampling=0, comment=b"bonjour"), "COM segment, .jpeg extension")
     add("prog_420_128x96_q60.jpg", encode(picture(128, 96, 93), quality=60, progressive=True, subsampling=2), "end-of-band runs over many blocks")
 
+    # one component with sampling factors above 1 (Pillow never writes these: the SOF sampling byte of a gray file is
+    # patched; the block count stays the same).  save_mcu_ligne_bw then repeats rows (src/decoder_utils.c:55-58).
+    for prog in (False, True):
+        g = encode(picture(32, 32, 94, gray=True), quality=80, progressive=prog)
+        sf = seg_of(g, 0xC2 if prog else 0xC0)
+        for hv in (0x22, 0x12, 0x21):
+            add(f"{'prog' if prog else 'base'}_gray_{hv >> 4}x{hv & 15}_32x32.jpg", g[:sf[1] + 11] + bytes([hv]) + g[sf[1] + 12:],
+                "gray with sampling factors above 1 (patched SOF)")
+
     # ---- the reference's own header fixtures (data files) -------------------------------------
     tf = os.path.join(REF, "test", "test_file")
     for f in sorted(os.listdir(tf)):

@@ -90,7 +90,9 @@ def test_default_output_name_next_to_input(gpu, tmp_path):
 
 
 @pytest.mark.parametrize("size,sub,prog", [((1024, 768), 2, True), ((1500, 1001), 1, True), ((2048, 2048), 0, False),
-                                            ((1920, 1080), 2, False)])
+                                            ((1920, 1080), 2, False),
+                                            ((4096, 4096), 1, True)],   # BASELINE.json configs[3]: progressive 4:2:2, 10 scans, end to end
+                         ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
 def test_larger_files_against_cpu_oracle(gpu, size, sub, prog):
     """Files encoded on the spot (Pillow): every scan's image from the GPU == the CPU oracle's."""
     Image = pytest.importorskip("PIL.Image")

@@ -112,6 +112,21 @@ def test_ragged_sizes_vs_oracle(gpu, samp):
             assert np.array_equal(want, got), (samp, w, h, aq)
 
 
+@pytest.mark.parametrize("samp", [((2, 2),), ((1, 2),), ((4, 1),), ((1, 4),), ((4, 4),)], ids=lambda s: f"{s[0][0]}x{s[0][1]}")
+def test_gray_with_sampling_above_one(gpu, samp):
+    """One component with sampling factors > 1: save_mcu_ligne_bw (src/decoder_utils.c:55-58) only reads the first
+    block row of each MCU row, rows 8.. of a band repeat rows 0..7.  Oracle pinned on the reference objects
+    (oracle/check_oracle_vs_ref.c); fast (power-of-two tile) and generic gray paths."""
+    for (w, h) in ((61, 37), (300, 70), (2048, 64), (4099, 33)):
+        d = helpers.oracle_desc(w, h, samp)
+        planes = helpers.synth_planes(d, 600 + w)
+        want = orc.backend_run(d, planes, QT)
+        assert np.array_equal(gpu.backend_run(helpers.to_gpu_desc(gpu, d), planes, QT), want), (samp, w, h)
+        if samp[0][1] > 1:
+            band = want[:8 * samp[0][1]]
+            assert np.array_equal(band[8:16], band[0:8])
+
+
 def test_out_stride_and_untouched_padding(gpu):
     d = helpers.oracle_desc(301, 50, ((2, 2), (1, 1), (1, 1)))
     planes = helpers.synth_planes(d, 42)
@@ -205,7 +220,8 @@ def test_every_chroma_pair_through_the_fused_kernel(gpu, samp):
 # ---- BASELINE.json sizes: stripes vs the oracle + size-independent properties -------------------
 
 BIG = {"c2_4096x4096_444": (4096, 4096, ((1, 1),) * 3), "c3_8192x8192_420": (8192, 8192, ((2, 2), (1, 1), (1, 1))),
-       "c4_4096x4096_422": (4096, 4096, ((2, 1), (1, 1), (1, 1))), "c1_512x512_gray": (512, 512, ((1, 1),))}
+       "c4_4096x4096_422": (4096, 4096, ((2, 1), (1, 1), (1, 1))), "c1_512x512_gray": (512, 512, ((1, 1),)),
+       "c5_1920x1080_420": (1920, 1080, ((2, 2), (1, 1), (1, 1)))}
 
 
 @pytest.mark.parametrize("name", sorted(BIG))
@@ -215,11 +231,11 @@ def test_baseline_sizes(gpu, name):
     planes = helpers.synth_planes(d, 0x5EED0000 + len(name))
     gd = helpers.to_gpu_desc(gpu, d)
     full = gpu.backend_run(gd, planes, QT)
-    # (1) MCU-row stripes (first, middle, last) against the oracle
-    band = d.max_v * 8
-    for m0 in sorted({0, d.nbmcuV // 2, d.nbmcuV - 1}):
-        want = orc.backend_run(d, planes, QT, mcu_rows=(m0, m0 + 1))
-        assert np.array_equal(full[m0 * band:(m0 + 1) * band], want[m0 * band:(m0 + 1) * band]), (name, m0)
+    # (1) the WHOLE raster: against the hash the compiled reference produced for this frame (oracle/make_golden.py)
+    #     and byte for byte against the oracle
+    gold = json.load(open(os.path.join(G, "meta.json")))["baseline_sizes"][name]
+    assert full.shape[0] == gold["rows"] and sha(full) == gold["sha256"], name
+    assert np.array_equal(full, orc.backend_run(d, planes, QT)), name
     # (2) stripe decomposition == whole frame (the multi-GPU sharding property): run the two halves
     #     as independent frames and concatenate
     half = d.nbmcuV // 2
@@ -258,6 +274,43 @@ def test_batch_equals_frame_by_frame(gpu):
     planes = [host[c][f * nb[c]:(f + 1) * nb[c]] for c in range(3)]
     want = orc.backend_run(d, planes, QT, mcu_rows=(10, 12))
     assert np.array_equal(got[f][160:192], want[160:192])
+
+
+def test_c5_batch_of_8192_frames_beyond_4GiB_offsets(gpu):
+    """BASELINE.json configs[4] at its stated size: 8192 frames of 1920x1080 4:2:0 in ONE launch (51 GB of planes,
+    51 GB of rasters, frame offsets far beyond 4 GiB).  Eight distinct frames are replicated on the device; every
+    frame f must equal frame f mod 8, and those eight equal the oracle."""
+    import torch
+    free, _total = torch.cuda.mem_get_info()
+    d = helpers.oracle_desc(1920, 1080, ((2, 2), (1, 1), (1, 1)))
+    gd = helpers.to_gpu_desc(gpu, d)
+    K, NF = 8, 8192
+    nb = [helpers.plane_shape(d, c)[0] for c in range(3)]
+    rows, rb = gpu.raster_rows(gd), gpu.raster_row_bytes(gd)
+    fb = rows * rb
+    need = NF * (sum(nb) * 128 + fb)
+    if free < need + (8 << 30):
+        pytest.skip(f"needs {need >> 30} GiB of free device memory, {free >> 30} GiB available")
+    host = [pyoracle.synth_blocks(nb[c] * K, 0xC5 + c) for c in range(3)]
+    dev = [torch.from_numpy(a).cuda().repeat(NF // K, 1) for a in host]     # frame f = frame f mod K
+    assert all(t.shape[0] == NF * nb[c] for c, t in enumerate(dev))
+    out = torch.empty(NF * fb, dtype=torch.uint8, device="cuda")
+    assert (NF - 1) * fb > (1 << 32) and (NF - 1) * nb[1] * 128 > (1 << 32)
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    gpu.backend_run_batch_device(gd, NF, [t.data_ptr() for t in dev], None, QT, out.data_ptr(), 0, 0, st.cuda_stream)
+    st.synchronize()
+    first = out[:K * fb]
+    G = 64                                                  # compare 64 groups of K frames at a time
+    v = out.view(NF // K, K * fb)
+    for g0 in range(0, NF // K, G):
+        assert bool((v[g0:g0 + G] == first).all()), f"a frame in groups {g0}..{g0 + G - 1} differs from its frame mod {K}"
+    got = first.cpu().numpy().reshape(K, rows, rb)
+    for f in range(K):
+        planes = [host[c][f * nb[c]:(f + 1) * nb[c]] for c in range(3)]
+        assert np.array_equal(got[f], orc.backend_run(d, planes, QT)), f
+    del dev, out, v, first
+    torch.cuda.empty_cache()
 
 
 def test_bench_line_contract(gpu):

@@ -134,3 +134,19 @@ def test_oracle_matches_reference_objects_when_present():
     d = helpers.oracle_desc(301, 97, ((2, 2), (1, 1), (1, 1)))
     planes = helpers.synth_planes(d, 9)
     assert np.array_equal(orc.backend_run(d, planes, QT), ref.backend_run(d, planes, QT))
+
+
+@pytest.mark.parametrize("name", ["c1_512x512_gray", "c5_1920x1080_420", "c2_4096x4096_444", "c4_4096x4096_422", "c3_8192x8192_420"])
+def test_oracle_whole_rasters_at_baseline_sizes(name):
+    """The restatement reproduces the compiled reference's whole raster (SHA-256 from oracle/make_golden.py) at every
+    BASELINE.json frame size -- the hashes the GPU suite compares the HIP path with."""
+    import json
+    gold = json.load(open(os.path.join(helpers.GOLDEN, "meta.json")))["baseline_sizes"][name]
+    d = helpers.oracle_desc(gold["width"], gold["height"], [tuple(s) for s in gold["sampling"]])
+    planes = helpers.synth_planes(d, gold["seed"])
+    out = pyoracle.oracle.backend_run(d, planes, helpers.qtables_ramp())
+    band = d.max_v * 8
+    assert out.shape[0] == gold["rows"]
+    assert hashlib.sha256(np.ascontiguousarray(out[:band]).tobytes()).hexdigest() == gold["sha256_first_band"]
+    assert hashlib.sha256(np.ascontiguousarray(out[-band:]).tobytes()).hexdigest() == gold["sha256_last_band"]
+    assert hashlib.sha256(out.tobytes()).hexdigest() == gold["sha256"]
