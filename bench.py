@@ -1,20 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- MPix/s of the fused IQZZ + IDCT + upsample + YCbCr->RGB back end on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4|c5] [--frames F]
+  python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4|c5|g1] [--frames F]
+                  [--scaling weak|strong] [--images M]
 
-A step = one pass of the hot path over one batch of F same-geometry frames (device-resident,
-distinct buffers, > 256 MiB in total so that nothing is served from the Infinity Cache), issued as
-ONE launch of jpeggpu_backend_run_batch_device through the C ABI.  For N > 1 every rank (one
-process per GPU, launched by torch.distributed.run) decodes its own batch of independent images --
-the path shards with no exchange step, so there is no data-path collective; RCCL is used only for
-the barrier and the max-over-ranks of the timing ("scaling": "weak").
+A step = one pass of the hot path over one batch of same-geometry frames (device-resident, distinct
+buffers, > 256 MiB in total so that nothing is served from the Infinity Cache), issued through the C ABI
+(jpeggpu_backend_run_batch_device).
+
+N > 1: one process per GPU.  When the script is started WITHOUT a launcher (no WORLD_SIZE in the environment) it
+starts N ranks itself -- python -m torch.distributed.run, as a child process, before anything touches a GPU -- and
+exits with the launcher's status; under a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE.  It refuses to run when
+fewer than N devices are visible: the line it prints always has n_gpus == --gpus.
+
+The path shards with no exchange step, so there is no data-path collective; the process group is used
+for the barrier, the max-over-ranks of the time and gathering per-rank launch times.
+  --scaling weak   (default) every rank decodes its own batch of F frames per step            -> "scaling": "weak"
+  --scaling strong the job is fixed and cut across the ranks (jpeg_decoder_amd/sharding.py)   -> "scaling": "strong"
+       c5: --images M (default 8192, BASELINE.json configs[4]) independent 1080p images, image i on rank i mod N;
+           a step = the whole job, each rank working through its images in launches of F frames
+       c2/c3/c4/g1: the F frames of a step are cut into MCU-row stripes, rank g gets rows [g*nbmcuV/N, (g+1)*nbmcuV/N)
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the field definitions).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,7 +41,7 @@ WORKLOADS = {
     "c3": ("8192x8192 4:2:0, 2x2 chroma upsampling fused into colour convert (configs[2])", 8192, 8192, ((2, 2), (1, 1), (1, 1)), 8),
     "c4": ("4096x4096 4:2:2, GPU part of the progressive config (configs[3])", 4096, 4096, ((2, 1), (1, 1), (1, 1)), 16),
     "g1": ("8192x8192 grayscale (save_mcu_ligne_bw path; not a BASELINE config, gray coverage only)", 8192, 8192, ((1, 1),), 8),
-    "c5": ("batch of 1920x1080 4:2:0 images (configs[4], per-GPU slice)", 1920, 1080, ((2, 2), (1, 1), (1, 1)), 256),
+    "c5": ("batch of 1920x1080 4:2:0 images (configs[4])", 1920, 1080, ((2, 2), (1, 1), (1, 1)), 256),
 }
 
 
@@ -38,10 +50,70 @@ def algorithmic_bytes(jg, d):
     return sum(jg.plane_blocks(d, c) * 128 for c in range(d.nbcomp)) + jg.raster_rows(d) * jg.raster_row_bytes(d)
 
 
+def host_cores():
+    """(cores this process may run on, cores of the machine)."""
+    try:
+        mine = len(os.sched_getaffinity(0))
+    except AttributeError:
+        mine = os.cpu_count() or 1
+    return mine, os.cpu_count() or mine
+
+
+def reference_stage_times(name, w, h, samp):
+    """jpeg2ppm_fast -t (the reference's own -Ofast binary and its own timers, src/baseline.c:224-228) on a real JPEG
+    of the workload's geometry encoded on the spot.  None when the binary (oracle/_ref, built where /root/reference
+    exists) or Pillow is missing."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "jpeg2ppm_fast")
+    if not os.path.exists(exe) or len(samp) not in (1, 3):
+        return None
+    try:
+        import io
+        import tempfile
+        import numpy as np
+        from PIL import Image
+    except ImportError:
+        return None
+    sub = {((1, 1),) * 3: 0, ((2, 1), (1, 1), (1, 1)): 1, ((2, 2), (1, 1), (1, 1)): 2}.get(tuple(samp))
+    if len(samp) == 3 and sub is None:
+        return None
+    # a bounded picture: at most ~8 MPix so that the run stays within a few seconds
+    hh = min(h, max(16, (8 << 20) // w // 16 * 16))
+    y, x = np.mgrid[0:hh, 0:w]
+    a = np.stack([(x + y) % 256, (x * 3 + y // 2) % 256, (x // 3 + y * 2) % 256], -1).astype(np.float64)
+    a += np.random.default_rng(5).normal(0, 12, a.shape)
+    im = Image.fromarray(np.clip(a, 0, 255).astype(np.uint8))
+    kw = {"quality": 90}
+    if len(samp) == 1:
+        im = im.convert("L")
+    else:
+        kw["subsampling"] = sub
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, "in.jpg")
+        im.save(src, "JPEG", **kw)
+        try:
+            r = subprocess.run([exe, "-t", "-o", os.path.join(tmp, "out.pnm"), src], capture_output=True, timeout=120)
+        except (subprocess.TimeoutExpired, OSError):
+            return None
+        if r.returncode != 0:
+            return None
+        t = {}
+        for line in r.stdout.decode("utf-8", "replace").splitlines():
+            if " : " in line and line.endswith(" s"):
+                k, v = line.rsplit(" : ", 1)
+                t[k.strip()] = float(v[:-2])
+        izz, idct, wr = t.get("IZZ"), t.get("IDCT"), t.get("Ecriture de l'image")
+        if None in (izz, idct, wr):
+            return None
+        back = izz + idct + wr
+        return {"binary": "oracle/_ref/jpeg2ppm_fast -t", "picture": f"{w}x{hh} q90 JPEG encoded on the spot ({os.path.getsize(src)} bytes)",
+                "izz_s": izz, "idct_s": idct, "write_s": wr, "vld_iquant_s": t.get("Décodage DC/AC et Quantification"),
+                "total_s": t.get("Décodage complet de l'image"), "backend_mpix_s": round(w * hh / back / 1e6, 2) if back > 0 else None,
+                "note": "back end = IZZ + IDCT + Ecriture timers (two gettimeofday per block and stage included, as the reference measures itself)"}
+
+
 def cpu_baseline(name, w, h, samp, qt, budget_s=12.0):
     """The reference's own back end (oracle/_ref, -Ofast objects = jpeg2ppm_fast's) timed on one host
     core over whole frames of the same workload until ~budget_s of CPU time is spent."""
-    import numpy as np
     from oracle import pyoracle
     from jpeg_decoder_amd import synth
     be, kind = pyoracle.load_ref("fast"), "reference"
@@ -71,10 +143,69 @@ def cpu_baseline(name, w, h, samp, qt, budget_s=12.0):
         if dt > budget_s * 0.85 or reps >= 64:
             break
     pix = reps * w * min(h, nrows * rows_px)
-    return {"value": round(pix / dt / 1e6, 2), "unit": "MPix/s", "cores": 1, "kind": kind,
+    mine, machine = host_cores()
+    v = pix / dt / 1e6
+    return {"value": round(v, 2), "unit": "MPix/s", "cores": 1, "kind": kind,
             "sample": f"{reps} x {nrows} MCU rows ({w}x{nrows * rows_px} px) of workload {name}, "
-                      f"{'reference -Ofast objects (oracle/_ref/libjpegref_fast.so)' if kind == 'reference' else 'oracle/liboracle_fast.so'}, "
-                      f"{dt:.1f} s on 1 core"}
+                      f"{'reference -Ofast objects (oracle/_ref/libjpegref_fast.so) driven by oracle/ref_driver.c' if kind == 'reference' else 'oracle/liboracle_fast.so'}, "
+                      f"{dt:.1f} s on 1 core",
+            "host_cores": machine, "host_cores_usable": mine,
+            "n_process": {"value": round(v * mine, 1), "processes": mine,
+                          "note": "EXTRAPOLATION, not measured: the reference is single-threaded (no threads anywhere in src/); "
+                                  "N independent processes on independent images / MCU-row stripes = N x the one-core figure"},
+            "jpeg2ppm_fast_t": reference_stage_times(name, w, h, samp)}
+
+
+def end_to_end(jg, np, d, qt, w, h, reps=3):
+    """jpeggpu_backend_run (host pointers: H2D + kernel + D2H, PCIe-bound) on ONE frame of the workload, caller memory
+    pageable (staged through pinned stripes) and pinned (jpeggpu_host_alloc: DMA in place).  Never the headline value."""
+    from jpeg_decoder_amd import synth
+    nb = [jg.plane_blocks(d, c) for c in range(d.nbcomp)]
+    rows, rb = jg.raster_rows(d), jg.raster_row_bytes(d)
+    nbytes = sum(nb) * 128 + rows * rb
+    planes = [synth.synth_blocks(nb[c], 0xE2E + c) for c in range(d.nbcomp)]
+    res = {"frame_bytes_in_plus_out": int(nbytes), "pcie_spec_GBps": 63.0}
+    out = np.empty((rows, rb), dtype=np.uint8)
+    best = None
+    for _ in range(reps + 1):
+        t0 = time.perf_counter()
+        jg.backend_run(d, planes, qt, out=out)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    res["pageable"] = {"ms": round(best * 1e3, 3), "MPix_s": round(w * h / best / 1e6, 1), "GBps": round(nbytes / best / 1e9, 2)}
+    held = []
+    try:
+        held = [jg.PinnedArray(p.shape, p.dtype) for p in planes] + [jg.PinnedArray(out.shape, out.dtype)]
+        for hp, p in zip(held, planes):
+            hp.array[...] = p
+        pp, po = [hp.array for hp in held[:-1]], held[-1].array
+        best = None
+        for _ in range(reps + 1):
+            t0 = time.perf_counter()
+            jg.backend_run(d, pp, qt, out=po)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        res["pinned"] = {"ms": round(best * 1e3, 3), "MPix_s": round(w * h / best / 1e6, 1), "GBps": round(nbytes / best / 1e9, 2)}
+        assert np.array_equal(po, out)
+        del pp, po
+    finally:
+        for hp in held:
+            hp.free()
+    return res
+
+
+def spawn_ranks(args):
+    """No launcher around us: start the N ranks as children (nothing here has touched a GPU yet) and pass their
+    status on."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.realpath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -83,109 +214,196 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--frames", type=int, default=0, help="frames per step (0 = workload default)")
+    ap.add_argument("--frames", type=int, default=0, help="frames per launch (0 = workload default)")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
+    ap.add_argument("--images", type=int, default=8192, help="strong scaling of c5: images in the whole job")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / sharding / reporting path only: gloo, no GPU, no kernel (CPU test of the N > 1 path)")
     ap.add_argument("--prewarm-ms", type=float, default=1500.0,
                     help="untimed launches before the W warmup steps until the chip's clock governor has settled "
                          "(launch time drifts 138 -> 178 -> 127 us over the first ~25 ms of load on MI355X)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        if not args.dry_run:
+            import torch     # device_count() does not initialise the GPU
+            n = torch.cuda.device_count()
+            if n < args.gpus:
+                raise SystemExit(f"--gpus {args.gpus} but only {n} GPU(s) visible")
+        raise SystemExit(spawn_ranks(args))
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(world_env or "1")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line printed must describe the run that happened")
 
     import numpy as np
     import torch
     import torch.distributed as dist
+    from jpeg_decoder_amd import sharding
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.dry_run:
+        if world > 1:
+            dist.init_process_group("gloo")
+    else:
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but {torch.cuda.device_count()} GPU(s) visible")
+        torch.cuda.set_device(local_rank)
+        if world > 1:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import jpeg_decoder_amd as jg
     from jpeg_decoder_amd import synth
-    jg.init(local_rank)
+    if not args.dry_run:
+        jg.init(local_rank)
 
     desc_text, w, h, samp, nf_default = WORKLOADS[args.workload]
     nf = args.frames or nf_default
-    d = jg.make_desc(w, h, samp)
+    d = jg.make_desc(w, h, samp)              # host-only geometry
+    full_rows = d.nbmcuV
     qt = synth.shaun_qtables()
+
+    # ---- what this rank does in one step -------------------------------------------------------------
+    # launches: list of frame counts; every launch works on its own buffers
+    strong = args.scaling == "strong"
+    if strong and args.workload == "c5":
+        my_images = sharding.shard_images(args.images, rank, world)           # image i -> rank i mod N
+        launches = [min(nf, len(my_images) - i) for i in range(0, len(my_images), nf)]
+        total_pixels_per_step = args.images * w * h                            # whole job, all ranks
+        shard_text = f"strong: {args.images} independent images, image i on rank i mod {world}, {len(my_images)} on this rank in launches of {nf}; no collective"
+    elif strong:
+        m0, m1 = sharding.shard_mcu_rows(full_rows, rank, world)               # MCU-row stripe of every frame
+        d.nbmcuV = m1 - m0
+        launches = [nf] if m1 > m0 else []
+        total_pixels_per_step = nf * w * h
+        shard_text = f"strong: {nf} frames per step cut into MCU-row stripes, rank g decodes rows [g*{full_rows}/{world}, (g+1)*{full_rows}/{world}); no collective"
+    else:
+        launches = [nf]
+        total_pixels_per_step = world * nf * w * h
+        shard_text = "weak: independent images per rank, no collective"
     nb = [jg.plane_blocks(d, c) for c in range(d.nbcomp)]
-    # independent images per rank: block index stream offset by (rank*nf + frame)
-    planes = []
-    for c in range(d.nbcomp):
-        host = np.empty((nf * nb[c], 64), dtype=np.int16)
-        for f in range(nf):
-            host[f * nb[c]:(f + 1) * nb[c]] = synth.synth_blocks(nb[c], 0x5EED0000 + c, (rank * nf + f) * nb[c], 0)
-        planes.append(torch.from_numpy(host).cuda())
     rows, rb = jg.raster_rows(d), jg.raster_row_bytes(d)
-    out = torch.empty(nf * rows * rb, dtype=torch.uint8, device="cuda")
-    ptrs = [t.data_ptr() for t in planes]
-    stream = torch.cuda.Stream()      # a real (non-NULL) HIP stream: kernels AND events go on it
+    frames_resident = sum(launches)
+    bytes_per_frame = algorithmic_bytes(jg, d)
 
-    def step():
-        jg.backend_run_batch_device(d, nf, ptrs, None, qt, out.data_ptr(), 0, 0, stream.cuda_stream)
+    kernel_ms, t_local = [], 0.0
+    if args.dry_run:
+        t_local = 1e-3 * args.steps * max(1, len(launches))
+        kernel_ms = [1.0] * (args.steps * max(1, len(launches)))
+    elif launches:
+        # distinct synthetic frames; beyond KMAX the buffers repeat frame f mod KMAX (replicated on the device: generating
+        # 51 GB of coefficients on the host would take minutes) -- every frame still has its own memory
+        KMAX = 32
+        kdist = min(frames_resident, KMAX)
+        planes = []
+        for c in range(d.nbcomp):
+            host = np.empty((kdist * nb[c], 64), dtype=np.int16)
+            for f in range(kdist):
+                host[f * nb[c]:(f + 1) * nb[c]] = synth.synth_blocks(nb[c], 0x5EED0000 + c, (rank * frames_resident + f) * nb[c], 0)
+            t = torch.from_numpy(host).cuda()
+            if frames_resident > kdist:
+                t = t.repeat((frames_resident + kdist - 1) // kdist, 1)[:frames_resident * nb[c]].contiguous()
+            planes.append(t)
+        out = torch.empty(frames_resident * rows * rb, dtype=torch.uint8, device="cuda")
+        stream = torch.cuda.Stream()      # a real (non-NULL) HIP stream: kernels AND events go on it
+        firsts = [sum(launches[:i]) for i in range(len(launches))]
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        def launch(i):
+            f0 = firsts[i]
+            jg.backend_run_batch_device(d, launches[i], [planes[c].data_ptr() + f0 * nb[c] * 128 for c in range(d.nbcomp)], None, qt,
+                                        out.data_ptr() + f0 * rows * rb, 0, 0, stream.cuda_stream)
 
-    t_pre = time.perf_counter()
-    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
-        for _ in range(20):
+        def step():
+            for i in range(len(launches)):
+                launch(i)
+
+        def fence():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        t_pre = time.perf_counter()
+        while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+            for _ in range(max(1, 20 // len(launches))):
+                step()
+            torch.cuda.synchronize()
+        for _ in range(args.warmup):
             step()
+        fence()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps * len(launches))]
+        t0 = time.perf_counter()
+        k = 0
+        for _ in range(args.steps):
+            for i in range(len(launches)):
+                a, b = ev[k]
+                k += 1
+                a.record(stream)
+                launch(i)
+                b.record(stream)
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    fence()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for a, b in ev:
-        a.record(stream)
-        step()
-        b.record(stream)
-    torch.cuda.synchronize()
-    t_local = time.perf_counter() - t0
-    fence()
-    kernel_ms = [a.elapsed_time(b) for a, b in ev]
-    tt = torch.tensor([t_local], dtype=torch.float64, device="cuda")
+        t_local = time.perf_counter() - t0
+        fence()
+        kernel_ms = [a.elapsed_time(b) for a, b in ev]
     if world > 1:
+        dev = "cpu" if args.dry_run else "cuda"
+        tt = torch.tensor([t_local], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    t_max = float(tt.item())
+        t_max = float(tt.item())
+        mine = torch.tensor([float(np.mean(kernel_ms)) * 1e3 if kernel_ms else 0.0], dtype=torch.float64, device=dev)
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+        per_rank_us = [round(float(x.item()), 2) for x in per_rank]
+    else:
+        t_max = t_local
+        per_rank_us = [round(float(np.mean(kernel_ms)) * 1e3, 2)]
 
-    pix_per_step = nf * w * h                       # nominal pixels, per rank
-    value = world * pix_per_step * args.steps / t_max / 1e6
-    launch_s = float(np.mean(kernel_ms)) / 1e3
-    bytes_per_launch = nf * algorithmic_bytes(jg, d)
-    achieved = bytes_per_launch / launch_s / 1e9
-    traffic = None
+    value = total_pixels_per_step * args.steps / t_max / 1e6
+    # roofline of the dominant kernel: full-size launches of this rank
+    full = [ms for j, ms in enumerate(kernel_ms) if launches and launches[j % len(launches)] == max(launches)]
+    launch_s = float(np.mean(full)) / 1e3 if full else float("nan")
+    bytes_per_launch = (max(launches) if launches else 0) * bytes_per_frame
+    achieved = bytes_per_launch / launch_s / 1e9 if full else 0.0
+    traffic, traffic_source = None, None
     tf = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-measured HBM bytes per launch, if collected
-    if os.path.exists(tf):
+    if os.path.exists(tf) and not strong:
         try:
             traffic = json.load(open(tf)).get(f"{args.workload}_f{nf}")
+            if traffic is not None:
+                traffic_source = ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                                  "(tools/prof_pmc.sh), collected separately, not measured in this run")
         except Exception:
             traffic = None
     res = {
         "metric": "MPix/s IQZZ+IDCT+upsample+YCbCr->RGB", "value": round(value, 1), "unit": "MPix/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(t_max / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+i32 (u8 out)", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {desc_text}", "frames_per_step_per_gpu": nf, "width": w, "height": h,
-                   "sampling": [list(s) for s in samp], "blocks_per_frame": int(sum(nb)), "sharding": "independent images per rank, no collective"},
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32+i32 (u8 out)",
+        "data": "synthetic" + (" (frames beyond 32 per rank repeat frame f mod 32, each in its own memory)" if frames_resident > 32 else ""),
+        "config": {"workload": f"{args.workload}: {desc_text}", "frames_per_launch": nf, "launches_per_step_rank0": len(launches),
+                   "width": w, "height": h, "sampling": [list(s) for s in samp], "blocks_per_frame_rank0": int(sum(nb)), "sharding": shard_text},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "backend_kernel", "bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(launch_s * 1e6, 2),
-                     "min_launch_us": round(min(kernel_ms) * 1e3, 2)},
+                     "min_launch_us": round(min(full) * 1e3, 2) if full else None, "per_rank_avg_launch_us": per_rank_us},
     }
+    if args.dry_run:
+        res["dry_run"] = True
     if os.environ.get("JPEGGPU_BENCH_TRACE") and rank == 0:
         print("launch_us:", " ".join(f"{x * 1e3:.0f}" for x in kernel_ms), file=sys.stderr)
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.workload, w, h, samp, qt)
-        else:
-            res["cpu_baseline"] = None
+        solo = world == 1 and not args.dry_run
+        res["cpu_baseline"] = cpu_baseline(args.workload, w, h, samp, qt) if solo and not args.no_cpu_baseline else None
+        if solo and not args.no_end_to_end:
+            try:
+                res["end_to_end"] = end_to_end(jg, np, jg.make_desc(w, h, samp), qt, w, h)
+            except Exception as e:      # reported, never fatal for the headline
+                res["end_to_end"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
