@@ -135,3 +135,41 @@ def test_reference_drivers_linked_against_the_compat_library(gpu, tmp_path, name
     r = subprocess.run([exe, "-o", str(out / "x.pnm"), os.path.join(JDIR, name)], capture_output=True, timeout=110)
     assert r.returncode == e["rc"], (r.returncode, r.stderr[-300:])
     _check_outputs(out, e)
+
+
+INTEGRATION_FILES = ["ref_shaun_the_sheep.jpeg", "ref_invader_normal.jpeg", "c1_gray_512x512_q90.jpg", "c4_prog422_160x120.jpg",
+                     "prog_420_61x47_q80.jpg", "base_444_17x9_q95_opt.jpg", "base_422_35x70_q30_opt.jpg", "prog_gray_2x2_32x32.jpg",
+                     "bad_truncated_scan.jpg", "bad_prog_truncated.jpg", "bad_dri.jpg", "flip_base_03.jpg"]
+
+
+@pytest.mark.parametrize("name", INTEGRATION_FILES)
+def test_integration_binding_compiled_as_c(gpu, tmp_path, name):
+    """INTEGRATION.md section 2 as a program (oracle/_ref/jpeg2ppm_integration, built by `make -C oracle integration`):
+    the reference's own main, header parser, VLD and bit reader, unmodified, with its two mode drivers replaced by
+    integration/{progressive,baseline}_jpeggpu.c -- contiguous pinned planes, ONE jpeggpu_backend_run per scan / image,
+    statuses through the erreur_t shim -- writes the files the all-CPU reference wrote, with the same exit status."""
+    exe = os.path.join(helpers.ROOT, "oracle", "_ref", "jpeg2ppm_integration")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/jpeg2ppm_integration was not built")
+    if name not in EXPECT:
+        pytest.skip(f"{name} is not among the fixtures")
+    e = EXPECT[name]
+    out = tmp_path / "o"
+    out.mkdir()
+    r = subprocess.run([exe, "-o", str(out / "x.pnm"), os.path.join(JDIR, name)], capture_output=True, timeout=110)
+    assert r.returncode == e["rc"], (r.returncode, r.stderr[-300:])
+    _check_outputs(out, e)
+
+
+def test_integration_binding_slow_idct_option(gpu, tmp_path):
+    """The same program under the reference's -f option (all_option.idct_fast = 0 -> jpeggpu_set_idct_fast(0))."""
+    exe = os.path.join(helpers.ROOT, "oracle", "_ref", "jpeg2ppm_integration")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/jpeg2ppm_integration was not built")
+    name = "c4_prog422_160x120.jpg"
+    e = dict(EXPECT[name], outputs=EXPECT[name]["outputs_slow"])
+    out = tmp_path / "o"
+    out.mkdir()
+    r = subprocess.run([exe, "-f", "-o", str(out / "x.pnm"), os.path.join(JDIR, name)], capture_output=True, timeout=110)
+    assert r.returncode == 0, r.stderr[-300:]
+    _check_outputs(out, e)
