@@ -278,8 +278,22 @@ void plan_backend(const jpeggpu_frame_desc_t *d, const jpeggpu_qtable_t *const q
    if (d->apply_iquant)
       for (int i = 0; i < 4; i++)
          if (qt[i]) pack_qtable(qt[i], p.qt[i]);
+   auto log2_exact = [](uint32_t v) { uint32_t s = 0; while ((1u << s) < v) s++; return (1u << s) == v ? s : 0xFFu; };
+   bool pow2 = log2_exact((uint32_t)d->max_h * 2) != 0xFFu;
+   for (int c = 0; c < d->nbcomp; c++) { const uint32_t s = log2_exact(d->comp[c].hs); p.hs_shift[c] = s == 0xFFu ? 0 : s; pow2 = pow2 && s != 0xFFu; }
+   p.mcu_q_shift = pow2 ? log2_exact((uint32_t)d->max_h * 2) : 0;
+   p.nbmcuH = d->nbmcuH; p.total_mcus = d->nbmcuH * d->nbmcuV;
    ld.tiles_per_row = (d->nbmcuH + T - 1) / T;
    ld.mcu_rows = d->nbmcuV;
+   // Linear tiling: when an MCU row is not a whole number of tiles (1920 pixels of 4:2:0 = 120 MCUs = 1.875 tiles) the
+   // last tile of every row would run with idle lanes; instead the frame's MCUs are tiled in raster order and a tile
+   // may run on into the next MCU row (one wrap point at most, since nbmcuH > T).
+   if (!tn.no_linear && pow2 && p.wave_uniform && p.wq_shift != 0xFFFFFFFFu && p.wq_shift >= 6 && fast_colour_layout(p) &&
+       d->nbmcuH > T && d->nbmcuH % T != 0 && (uint64_t)d->nbmcuH * d->nbmcuV < (1ull << 31)) {
+      p.linear = 1;
+      ld.tiles_per_row = (p.total_mcus + T - 1) / T;
+      ld.mcu_rows = 1;
+   }
    ld.threads = (p.B + 63) / 64 * 64;                 // one thread per block
    ld.lds_bytes = (size_t)ld.threads * 64 + 512;
    if (tn.diag_lds_bytes > ld.lds_bytes && tn.diag_lds_bytes <= 64 * 1024) ld.lds_bytes = tn.diag_lds_bytes;
@@ -315,6 +329,7 @@ int run_device(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, uint32_t nfram
       int rc = ensure_slow_coef(ctx, &p.slow_coef); if (rc) return rc;
    }
    if (nframes > 65535 || d->nbmcuV > 65535) return fail(JPEGGPU_ERR_INVALID_ARG, "nframes / nbmcuV above 65535");
+   if (p.slow_coef && p.linear) { p.linear = 0; ld.tiles_per_row = (d->nbmcuH + p.T - 1) / p.T; ld.mcu_rows = d->nbmcuV; }   // "-f": generic pixel phase
    ld.frames = nframes;
    HIP_TRY(launch_backend(p, ld, s));
    return 0;

@@ -37,12 +37,18 @@ struct BackendParams {
    uint32_t hf[3], vf[3];          // upsampling factors max_h/hs, max_v/vs (src/decoder_utils.c:102-107)
    uint32_t plane_off[3];          // LDS byte offset of component c's u8 plane
    uint32_t idq[3];
+   uint32_t hs_shift[3];           // log2(hs) when hs is a power of two, else 0 (linear tiling needs powers of two)
+   uint32_t mcu_q_shift;           // log2(quads of 4 pixels per MCU width) = log2(max_h * 2) when that is a power of two
+   uint32_t linear;                // 1: a tile is T consecutive MCUs of the FRAME in raster order (grid.x = tiles per frame, grid.y = 1)
+   uint32_t nbmcuH;                // MCUs per MCU row
+   uint32_t total_mcus;            // nbmcuH * nbmcuV
    uint32_t qt[4][32];             // quantisation tables, zigzag order, two uint16 per word
 };
 
 struct LaunchDims { uint32_t tiles_per_row, mcu_rows, frames, threads; size_t lds_bytes; };
 
 hipError_t launch_backend(const BackendParams &p, const LaunchDims &d, hipStream_t s);
+bool fast_colour_layout(const BackendParams &p);   // true: a sub-sampling-specific pixel phase handles this layout
 
 // Device staging of jpeggpu_backend_run_noalloc: a file-scope __device__ array in kernels.hip (one copy per GPU).
 // static_scratch() returns ITS DEVICE ADDRESS on <device> (hipGetSymbolAddress, once per device, cached).

@@ -88,6 +88,113 @@ __device__ __forceinline__ void store_rgb_quad(uint8_t *dst, uint32_t w0, uint32
    }
 }
 
+// Colour conversion of one item: 4 pixels wide x VFC rows.  cbw / crw hold the item's chroma samples (HFC = 1: four
+// bytes, one per pixel; HFC = 2: two bytes, each under two pixels, upper half made unlike the special pair by the
+// caller), yy[v] the four luma bytes of row v.  w[v] = the 12 output bytes of row v.
+template <int HFC, int VFC>
+__device__ __forceinline__ void convert_item(const uint32_t (&yy)[VFC], uint32_t cbw, uint32_t crw, uint32_t (&w)[VFC][3]) {
+#if defined(JM_DIAG_NOCOLOR)
+   if (true) {
+#pragma unroll
+      for (int v = 0; v < VFC; v++) { w[v][0] = yy[v]; w[v][1] = cbw; w[v][2] = crw; }
+   } else
+#endif
+   if (__builtin_expect(__any(has_special_pair(cbw, crw)), 0)) {
+      // exact per-pixel form (the y-dependent green offset of (cb,cr) = (28,228))
+#pragma unroll
+      for (int v = 0; v < VFC; v++) {
+         uint32_t px[4];
+#pragma unroll
+         for (int i = 0; i < 4; i++) {
+            const int ci = (HFC == 1) ? i : (i >> 1);
+            px[i] = ycc_to_rgb((yy[v] >> (8 * i)) & 0xFF, chroma_offsets((cbw >> (8 * ci)) & 0xFF, (crw >> (8 * ci)) & 0xFF));
+         }
+         w[v][0] = px[0] | (px[1] << 24); w[v][1] = (px[1] >> 8) | (px[2] << 16); w[v][2] = (px[2] >> 16) | (px[3] << 8);
+      }
+   } else {
+      const ChromaPairs o = chroma_pairs<HFC>(cbw ^ 0x80808080u, crw ^ 0x80808080u);   // bytes become cb-128, cr-128 (int8)
+#pragma unroll
+      for (int v = 0; v < VFC; v++) rgb_quad_pk(yy[v], o, w[v]);
+   }
+}
+
+// Where a tile sits in its frame.  A tile is T consecutive MCUs: of one MCU row (column c0 .. c0+T-1 of row m0), or --
+// "linear" tiling, for frames whose MCU rows are not a whole number of tiles -- T consecutive MCUs in raster order,
+// running on into the next MCU row after `wrapj` of them.  nvalid < T only for the last tile of a linear frame.
+struct TileGeom { uint32_t m0, c0, wrapj, nvalid; };
+
+// Phase 2 for the sub-sampling-specific layouts when a tile row is at least 64 quads wide: every WAVE takes whole
+// runs of 64 consecutive quads (256 pixels of one raster row x VFC rows), so the row, the LDS offsets and the raster
+// address of a run are wave-uniform (SALU) and a lane adds only its own 4 / 12 byte offsets.  A run that lies inside
+// one MCU row and inside the frame stores 768 contiguous bytes per row from a scalar base; a run that straddles the
+// end of an MCU row (linear tiling), the right edge of the frame or the end of the frame takes the per-lane form.
+template <int HFC, int VFC>
+__device__ __forceinline__ void pixel_phase_runs(const BackendParams &p, const uint8_t *lds, uint32_t tid, uint32_t nt, const TileGeom &g,
+                                                 uint32_t frame) {
+   const uint32_t ws = p.wq_shift;                           // log2(quads per tile row), >= 6 here
+   const uint32_t rs = ws - 6;                               // log2(runs per tile row)
+   const uint32_t nruns = (p.tile_rows / VFC) << rs;
+   const uint32_t nwaves = nt >> 6;
+   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+   const uint32_t l = tid & 63;
+   const uint32_t qs = p.mcu_q_shift;                        // log2(quads per MCU): 1, 2 or 3
+   const uint32_t P = 64u >> qs;                             // MCUs per run
+   const uint32_t mcu_w = 4u << qs;                          // pixels per MCU
+   const uint32_t stride = (uint32_t)p.out_stride;           // <= 2^26 (run_device)
+   const uint32_t band = p.tile_rows * stride;               // bytes from one MCU row's band to the next (<= 2^31)
+   uint8_t *base0 = static_cast<uint8_t *>(p.out) + (size_t)frame * p.out_frame_stride + (size_t)g.m0 * band;
+   const uint32_t pitch0 = p.tile_w;
+   const uint32_t lc = l * (4 / HFC), ly = l * 4, l12 = l * 12;
+   const uint32_t first_row = min(g.wrapj, g.nvalid);        // tile MCUs [0, first_row) lie in MCU row m0
+   for (uint32_t run = wave; run < nruns; run += nwaves) {
+      const uint32_t yi = run >> rs, seg = run & ((1u << rs) - 1);
+      const uint32_t y = yi * VFC;
+      const uint32_t ja = seg * P;                           // first tile MCU of the run
+      if (ja >= g.nvalid) continue;
+      // where the run's 256 pixels go, if that is the same raster row for all of them
+      uint32_t xs = 0, rowoff = 0;
+      bool whole = false;
+      if (ja + P <= first_row) { xs = (g.c0 + ja) * mcu_w; whole = xs + 256 <= p.width; if (xs >= p.width) continue; }
+      else if (ja >= g.wrapj && ja + P <= g.nvalid) { xs = (ja - g.wrapj) * mcu_w; rowoff = band; whole = xs + 256 <= p.width; if (xs >= p.width) continue; }
+      const uint32_t it0 = (yi << ws) + (seg << 6);          // item index of lane 0 = word offset of its chroma samples
+      uint32_t cbw, crw;
+      if (HFC == 1) {
+         cbw = *reinterpret_cast<const uint32_t *>(lds + (p.plane_off[1] + it0 * 4 + lc));
+         crw = *reinterpret_cast<const uint32_t *>(lds + (p.plane_off[2] + it0 * 4 + lc));
+      } else {
+         cbw = *reinterpret_cast<const uint16_t *>(lds + (p.plane_off[1] + it0 * 2 + lc));
+         crw = *reinterpret_cast<const uint16_t *>(lds + (p.plane_off[2] + it0 * 2 + lc));
+         cbw |= 0x01010000u;   // unused byte lanes can never look like the special pair
+      }
+      const uint32_t y0 = p.plane_off[0] + (((y << ws) + (seg << 6)) << 2);
+      uint32_t yy[VFC];
+#pragma unroll
+      for (int v = 0; v < VFC; v++) yy[v] = *reinterpret_cast<const uint32_t *>(lds + (y0 + v * pitch0 + ly));
+      uint32_t w[VFC][3];
+      convert_item<HFC, VFC>(yy, cbw, crw, w);
+      if (whole) {
+         uint8_t *rowbase = base0 + ((size_t)rowoff + (size_t)y * stride + (size_t)xs * 3);   // wave-uniform
+#pragma unroll
+         for (int v = 0; v < VFC; v++) {
+            typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+            __builtin_nontemporal_store(u32x3{w[v][0], w[v][1], w[v][2]},
+                                        reinterpret_cast<u32x3 __attribute__((aligned(JM_STORE_ALIGN))) *>(rowbase + (size_t)v * stride + l12));
+         }
+      } else {
+         const uint32_t j = ja + (l >> qs);
+         const bool r2 = j >= g.wrapj;
+         const uint32_t col = r2 ? j - g.wrapj : g.c0 + j;
+         const uint32_t x = col * mcu_w + (l & ((1u << qs) - 1)) * 4;
+         if (j < g.nvalid && x < p.width) {
+            const uint32_t n = min(4u, p.width - x);
+            uint8_t *dst = base0 + ((r2 ? band : 0u) + y * stride + x * 3);
+#pragma unroll
+            for (int v = 0; v < VFC; v++) store_rgb_quad(dst + v * stride, w[v][0], w[v][1], w[v][2], n);
+         }
+      }
+   }
+}
+
 // Phase 2 of one tile: upsample + colour convert + store, from the u8 planes in LDS.
 template <int HFC, int VFC>
 __device__ __forceinline__ void pixel_phase(const BackendParams &p, const uint8_t *lds, uint32_t tid, uint32_t nt, uint32_t tile,
@@ -179,49 +286,7 @@ __device__ __forceinline__ void pixel_phase(const BackendParams &p, const uint8_
 #pragma unroll
          for (int v = 0; v < VFC; v++) yy[v] = *reinterpret_cast<const uint32_t *>(yrow + v * pitch0);
          uint32_t w[VFC][3];
-#if defined(JM_DIAG_NOCOLOR)
-         if (true) {
-#pragma unroll
-            for (int v = 0; v < VFC; v++) { w[v][0] = yy[v]; w[v][1] = cbw; w[v][2] = crw; }
-         } else
-#endif
-         if (__builtin_expect(__any(has_special_pair(cbw, crw)), 0)) {
-            // exact per-pixel form (the y-dependent green offset of (cb,cr) = (28,228))
-#pragma unroll
-            for (int v = 0; v < VFC; v++) {
-               uint32_t px[4];
-#pragma unroll
-               for (int i = 0; i < 4; i++) {
-                  const int ci = (HFC == 1) ? i : (i >> 1);
-                  px[i] = ycc_to_rgb((yy[v] >> (8 * i)) & 0xFF, chroma_offsets((cbw >> (8 * ci)) & 0xFF, (crw >> (8 * ci)) & 0xFF));
-               }
-               w[v][0] = px[0] | (px[1] << 24); w[v][1] = (px[1] >> 8) | (px[2] << 16); w[v][2] = (px[2] >> 16) | (px[3] << 8);
-            }
-         } else {
-#if defined(JM_COLOR_SCALAR)
-            Off3 o[4 / HFC];
-            const uint32_t cbs = cbw ^ 0x80808080u, crs = crw ^ 0x80808080u;   // bytes become cb-128, cr-128 (int8)
-#pragma unroll
-            for (int ci = 0; ci < 4 / HFC; ci++) o[ci] = chroma_off3((int)(int8_t)(cbs >> (8 * ci)), (int)(int8_t)(crs >> (8 * ci)));
-#pragma unroll
-            for (int v = 0; v < VFC; v++) {
-               int r[4], g[4], b[4];
-#pragma unroll
-               for (int i = 0; i < 4; i++) {
-                  const int ci = (HFC == 1) ? i : (i >> 1);
-                  const int ys = (yy[v] >> (8 * i)) & 0xFF;
-                  r[i] = clamp8(ys + o[ci].r); g[i] = clamp8(ys + o[ci].g); b[i] = clamp8(ys + o[ci].b);
-               }
-               w[v][0] = r[0] | (g[0] << 8) | (b[0] << 16) | (r[1] << 24);
-               w[v][1] = g[1] | (b[1] << 8) | (r[2] << 16) | (g[2] << 24);
-               w[v][2] = b[2] | (r[3] << 8) | (g[3] << 16) | (b[3] << 24);
-            }
-#else
-            const ChromaPairs o = chroma_pairs<HFC>(cbw ^ 0x80808080u, crw ^ 0x80808080u);   // bytes become cb-128, cr-128 (int8)
-#pragma unroll
-            for (int v = 0; v < VFC; v++) rgb_quad_pk(yy[v], o, w[v]);
-#endif
-         }
+         convert_item<HFC, VFC>(yy, cbw, crw, w);
 #pragma unroll
          for (int v = 0; v < VFC; v++)
             store_rgb_quad(tile_out + ((y + v) * stride + x * 3), w[v][0], w[v][1], w[v][2], n);
@@ -320,7 +385,21 @@ template <int HFC, int VFC, bool SLOW>   // chroma factors; 0 = generic path (an
 __device__ __forceinline__ void backend_body(const BackendParams &p) {
    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
    const uint32_t tid = threadIdx.x, nt = blockDim.x;
-   const uint32_t tile = blockIdx.x, m = blockIdx.y, frame = blockIdx.z;
+   const uint32_t frame = blockIdx.z;
+   // the tile's place in the frame (all scalar): T MCUs of MCU row blockIdx.y, or (linear tiling) MCUs
+   // [blockIdx.x * T, + T) of the frame in raster order
+   uint32_t tile = blockIdx.x, m = blockIdx.y;
+   TileGeom geo;
+   if (p.linear) {
+      const uint32_t g0 = tile * p.T;
+      geo.m0 = g0 / p.nbmcuH;
+      geo.c0 = g0 - geo.m0 * p.nbmcuH;
+      geo.wrapj = p.nbmcuH - geo.c0;
+      geo.nvalid = min(p.T, p.total_mcus - g0);
+      m = geo.m0;
+   } else {
+      geo.m0 = m; geo.c0 = tile * p.T; geo.wrapj = 0x7FFFFFFFu; geo.nvalid = p.T;
+   }
 #if defined(JM_DIAG_STAMP)
    const long long ts0 = __builtin_amdgcn_s_memtime();
    const long long tr0 = __builtin_amdgcn_s_memrealtime();
@@ -341,10 +420,15 @@ __device__ __forceinline__ void backend_body(const BackendParams &p) {
       uint32_t by = 0;
       if (vs > 1) by = (uint32_t)(r >= bw) + (uint32_t)(r >= 2 * bw) + (uint32_t)(r >= 3 * bw);
       const uint32_t bxl = r - by * bw;
-      const uint32_t col = min(tile * bw + bxl, nbH - 1);   // lanes right of the plane read its last column: never stored
+      // the block's MCU row: the tile's first one, or (linear tiling) the next one for the MCUs after the wrap point
+      const uint32_t hsh = p.hs_shift[c];
+      const uint32_t j = bxl >> hsh;                        // MCU of the tile this block belongs to
+      const bool r2 = j >= geo.wrapj && j < geo.nvalid;
+      uint32_t col = r2 ? bxl - (geo.wrapj << hsh) : (geo.c0 << hsh) + bxl;
+      col = min(col, nbH - 1);                              // lanes right of the plane / past the frame's last MCU read a valid block: never stored
       const uint8_t *base = static_cast<const uint8_t *>(p.coef[c]) + (size_t)frame * p.coef_frame_stride[c] +
-                            (size_t)m * vs * nbH * 128;      // uniform; one MCU row of a plane is < 2^32 bytes
-      const uint4 *src = reinterpret_cast<const uint4 *>(base + (by * nbH + col) * 128u);
+                            (size_t)m * vs * nbH * 128;      // uniform; two MCU rows of a plane are < 2^32 bytes
+      const uint4 *src = reinterpret_cast<const uint4 *>(base + (((r2 ? vs : 0u) + by) * nbH + col) * 128u);
       uint4 v[8];
 #pragma unroll
       for (int i = 0; i < 8; i++) v[i] = src[i];   // NOT non-temporal: a lane's 8 loads share one line (nt: 1.6x slower)
@@ -427,7 +511,11 @@ __device__ __forceinline__ void backend_body(const BackendParams &p) {
    const long long ts3 = __builtin_amdgcn_s_memtime();
 #endif
 #if !defined(JM_DIAG_NOPHASE2)
-   pixel_phase<HFC, VFC>(p, lds, tid, nt, tile, m, frame);
+#if !defined(JM_NO_RUNS)
+   if (HFC != 0 && p.wq_shift >= 6) pixel_phase_runs<(HFC ? HFC : 1), (VFC ? VFC : 1)>(p, lds, tid, nt, geo, frame);
+   else
+#endif
+      pixel_phase<HFC, VFC>(p, lds, tid, nt, tile, m, frame);
 #endif
 #if defined(JM_DIAG_STAMP)
    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -450,11 +538,18 @@ __global__ void __launch_bounds__(MAXT, JM_WAVES_PER_EU) backend_kernel(const Ba
 // the "-f" variant: generic pixel phase, no occupancy target (the direct transform keeps the block in 64 VGPRs)
 __global__ void __launch_bounds__(JM_MAX_THREADS) backend_kernel_slow(const BackendParams p) { backend_body<0, 0, true>(p); }
 
+// Layouts with a sub-sampling-specific pixel phase: three components, Y at full resolution, Cb and Cr sharing factors of
+// 1 or 2, and a tile row that is a power of two wide.
+bool fast_colour_layout(const BackendParams &p) {
+   return !p.slow_coef && p.nbcomp == 3 && p.wq_shift != 0xFFFFFFFFu && p.hf[0] == 1 && p.vf[0] == 1 && p.hf[1] == p.hf[2] &&
+          p.vf[1] == p.vf[2] && (p.hf[1] == 1 || p.hf[1] == 2) && (p.vf[1] == 1 || p.vf[1] == 2);
+}
+
 typedef void (*BackendFn)(const BackendParams);
 static BackendFn pick_kernel(const BackendParams &p, uint32_t threads) {
    if (p.slow_coef) return (BackendFn)backend_kernel_slow;
 #define JM_PICK(H, V) (threads <= 256 ? (BackendFn)backend_kernel<H, V, 256> : (BackendFn)backend_kernel<H, V, JM_MAX_THREADS>)
-   if (p.nbcomp == 3 && p.wq_shift != 0xFFFFFFFFu && p.hf[0] == 1 && p.vf[0] == 1 && p.hf[1] == p.hf[2] && p.vf[1] == p.vf[2]) {
+   if (fast_colour_layout(p)) {
       const uint32_t h = p.hf[1], v = p.vf[1];
       if (h == 1 && v == 1) return JM_PICK(1, 1);
       if (h == 2 && v == 1) return JM_PICK(2, 1);
@@ -466,8 +561,9 @@ static BackendFn pick_kernel(const BackendParams &p, uint32_t threads) {
 }
 
 hipError_t launch_backend(const BackendParams &p, const LaunchDims &d, hipStream_t s) {
-   dim3 grid(d.tiles_per_row, d.mcu_rows, d.frames), block(d.threads);
+   dim3 grid(d.tiles_per_row, d.mcu_rows, d.frames), block(d.threads);   // linear tiling: tiles of the frame x 1
    if (d.threads > JM_MAX_THREADS) return hipErrorInvalidConfiguration;
+   if (p.linear && (!fast_colour_layout(p) || !p.wave_uniform || p.wq_shift < 6 || d.mcu_rows != 1)) return hipErrorInvalidConfiguration;
    BackendFn k = pick_kernel(p, d.threads);
    if (d.lds_bytes > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d.lds_bytes);

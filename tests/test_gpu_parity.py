@@ -166,6 +166,49 @@ def test_other_tilings_and_prologues(gpu, env):
         gpu.reload_tuning()
 
 
+@pytest.mark.parametrize("samp", [((1, 1),) * 3, ((2, 2), (1, 1), (1, 1)), ((2, 1), (1, 1), (1, 1)), ((1, 2), (1, 1), (1, 1))],
+                         ids=["444", "420", "422", "440"])
+def test_linear_tiling(gpu, samp):
+    """Frames whose MCU rows are not a whole number of 64-MCU tiles are tiled in raster order (a tile runs on into the
+    next MCU row; the last tile of the frame is partly empty).  Widths that crop the last MCU, padded rows, several
+    frames per launch; the knob JPEGGPU_NO_LINEAR gives the per-row tiling, which must produce the same bytes."""
+    import torch
+    mw = samp[0][0] * 8
+    for (w, h) in ((65 * mw, 40), (65 * mw - 5, 8 * samp[0][1] * 3), (120 * mw, 8 * samp[0][1] * 5), (200 * mw - mw + 1, 70), (129 * mw - 3, 8 * samp[0][1])):
+        d = helpers.oracle_desc(w, h, samp)
+        assert d.nbmcuH > 64 and d.nbmcuH % 64
+        planes = helpers.synth_planes(d, 800 + w % 97)
+        want = orc.backend_run(d, planes, QT)
+        gd = helpers.to_gpu_desc(gpu, d)
+        assert np.array_equal(gpu.backend_run(gd, planes, QT), want), (samp, w, h)
+        stride = want.shape[1] + 29
+        buf = np.full((want.shape[0], stride), 0xEE, dtype=np.uint8)
+        got = gpu.backend_run(gd, planes, QT, out=buf, out_stride=stride)
+        assert np.array_equal(got[:, :want.shape[1]], want) and np.all(buf[:, want.shape[1]:] == 0xEE)
+    # three frames in one launch, and the same with the per-row tiling
+    nb = [helpers.plane_shape(d, c)[0] for c in range(3)]
+    host = [pyoracle.synth_blocks(nb[c] * 3, 850 + c) for c in range(3)]
+    dev = [torch.from_numpy(a).cuda() for a in host]
+    rows, rb = gpu.raster_rows(gd), gpu.raster_row_bytes(gd)
+    outs = []
+    for knob in (None, "1"):
+        if knob:
+            os.environ["JPEGGPU_NO_LINEAR"] = knob
+        gpu.reload_tuning()
+        try:
+            out = torch.zeros(3 * rows * rb, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            gpu.backend_run_batch_device(gd, 3, [t.data_ptr() for t in dev], None, QT, out.data_ptr())
+            gpu.synchronize()
+            outs.append(out.cpu().numpy().reshape(3, rows, rb))
+        finally:
+            os.environ.pop("JPEGGPU_NO_LINEAR", None)
+            gpu.reload_tuning()
+    assert np.array_equal(outs[0], outs[1])
+    for f in range(3):
+        assert np.array_equal(outs[0][f], orc.backend_run(d, [host[c][f * nb[c]:(f + 1) * nb[c]] for c in range(3)], QT)), f
+
+
 def test_full_int16_range_and_wrap(gpu):
     d = helpers.oracle_desc(640, 64, ((2, 2), (1, 1), (1, 1)), idq=[2, 2, 2])
     planes = helpers.synth_planes(d, 7, kind=2)
