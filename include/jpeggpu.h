@@ -184,6 +184,25 @@ int jpeggpu_ctx_backend_run_batch_device(jpeggpu_ctx_t *ctx, const jpeggpu_frame
                                          void *hip_stream);
 int jpeggpu_ctx_synchronize(jpeggpu_ctx_t *ctx, void *hip_stream);
 
+/* Several GPUs from ONE process (the path shards with no exchange step, so there is no collective).
+ * One context per device (several contexts on one device also work); the library runs one host thread per context,
+ * each through its context's pipelined host-pointer form, and returns the first error.  No counterpart in the
+ * reference (one thread, no device); the unit of work is the reference's own: one MCU row for the writers
+ * (src/decoder_utils.c:65-90), one image for the drivers (src/jpeg2ppm.c:62-138).
+ *   jpeggpu_multi_backend_run       ONE frame cut into contiguous MCU-row stripes: context g decodes MCU rows
+ *                                   [g*nbmcuV/n, (g+1)*nbmcuV/n) of every component and writes the matching band of <out>
+ *                                   (replicate upsampling has no halo, src/decoder_utils.c:72-80)
+ *   jpeggpu_multi_backend_run_batch <nframes> independent frames of one geometry, host memory, frame f's plane c at
+ *                                   (char*)coef[c] + f*coef_frame_stride[c] (0 = dense), raster at out + f*out_frame_stride:
+ *                                   frame f goes to context f mod n                                                     */
+int jpeggpu_multi_backend_run(jpeggpu_ctx_t *const *ctxs, int nctx, const jpeggpu_frame_desc_t *desc,
+                              const jpeggpu_blocl16_t *const coef[3], const jpeggpu_qtable_t *const qtables[4],
+                              uint8_t *out, size_t out_stride);
+int jpeggpu_multi_backend_run_batch(jpeggpu_ctx_t *const *ctxs, int nctx, const jpeggpu_frame_desc_t *desc, uint32_t nframes,
+                                    const jpeggpu_blocl16_t *const coef[3], const size_t coef_frame_stride[3],
+                                    const jpeggpu_qtable_t *const qtables[4],
+                                    uint8_t *out, size_t out_stride, size_t out_frame_stride);
+
 /* Allocation-free variant of jpeggpu_backend_run (host pointers in and out, synchronous, same bytes).
  * NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot allocate device memory -- code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc.  Nothing on its path calls hipMalloc,

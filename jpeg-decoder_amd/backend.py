@@ -98,6 +98,9 @@ lib.jpeggpu_ctx_backend_run.argtypes = [_vp] + lib.jpeggpu_backend_run.argtypes
 lib.jpeggpu_ctx_backend_run_device.argtypes = [_vp] + lib.jpeggpu_backend_run_device.argtypes
 lib.jpeggpu_ctx_backend_run_batch_device.argtypes = [_vp] + lib.jpeggpu_backend_run_batch_device.argtypes
 lib.jpeggpu_ctx_synchronize.argtypes = [_vp, _vp]
+lib.jpeggpu_multi_backend_run.argtypes = [C.POINTER(_vp), C.c_int, C.POINTER(FrameDesc), C.POINTER(_vp), C.POINTER(_vp), _vp, _sz]
+lib.jpeggpu_multi_backend_run_batch.argtypes = [C.POINTER(_vp), C.c_int, C.POINTER(FrameDesc), C.c_uint32, C.POINTER(_vp), C.POINTER(_sz),
+                                                C.POINTER(_vp), _vp, _sz, _sz]
 lib.jpeggpu_host_alloc.argtypes = [_sz]
 lib.jpeggpu_host_alloc.restype = _vp
 lib.jpeggpu_host_free.argtypes = [_vp]
@@ -242,6 +245,32 @@ def backend_run_batch_device(desc, nframes, d_coef, coef_frame_stride, qtables, 
     else:
         _check(lib.jpeggpu_backend_run_batch_device(C.byref(desc), nframes, cp, fs, qp, _vp(int(d_out)), out_stride,
                                                     out_frame_stride, _vp(stream or 0)))
+
+
+def multi_backend_run(ctxs, desc, coef, qtables, out=None, out_stride=0):
+    """jpeggpu_multi_backend_run: one frame, MCU-row stripes over the contexts (one host thread each)."""
+    planes = [np.ascontiguousarray(coef[c], dtype=np.int16) for c in range(desc.nbcomp)]
+    cp = (_vp * 3)(*([a.ctypes.data for a in planes] + [None] * (3 - len(planes))))
+    qp, keep = _qt_array(qtables)
+    rows, rb = raster_rows(desc), raster_row_bytes(desc)
+    stride = out_stride or rb
+    if out is None:
+        out = np.zeros((rows, stride), dtype=np.uint8)
+    hs = (_vp * len(ctxs))(*[c.handle for c in ctxs])
+    _check(lib.jpeggpu_multi_backend_run(hs, len(ctxs), C.byref(desc), cp, qp, out.ctypes.data, out_stride))
+    return out[:rows, :stride]
+
+
+def multi_backend_run_batch(ctxs, desc, nframes, coef, qtables):
+    """jpeggpu_multi_backend_run_batch: coef[c] = (nframes * blocks_c, 64) int16, frame-major; returns (nframes, rows, row_bytes)."""
+    planes = [np.ascontiguousarray(coef[c], dtype=np.int16) for c in range(desc.nbcomp)]
+    cp = (_vp * 3)(*([a.ctypes.data for a in planes] + [None] * (3 - len(planes))))
+    qp, keep = _qt_array(qtables)
+    rows, rb = raster_rows(desc), raster_row_bytes(desc)
+    out = np.zeros((nframes, rows, rb), dtype=np.uint8)
+    hs = (_vp * len(ctxs))(*[c.handle for c in ctxs])
+    _check(lib.jpeggpu_multi_backend_run_batch(hs, len(ctxs), C.byref(desc), nframes, cp, None, qp, out.ctypes.data, 0, 0))
+    return out
 
 
 class Context:

@@ -13,6 +13,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
 
 #include "../../include/jpeggpu.h"
 #include "kernels.h"
@@ -529,6 +532,71 @@ int jpeggpu_ctx_backend_run(jpeggpu_ctx_t *ctx, const jpeggpu_frame_desc_t *d, c
                             const jpeggpu_qtable_t *const qt[4], uint8_t *out, size_t out_stride) {
    int rc = bind(ctx); if (rc) return rc;
    return ctx_backend_run(ctx, d, coef, qt, out, out_stride);
+}
+
+// ---- several GPUs from one process: independent shards, one host thread per context, no exchange step ----
+
+// (ii) ONE frame cut into contiguous MCU-row stripes: context g decodes rows [g*nbmcuV/n, (g+1)*nbmcuV/n) of every component
+// and writes the matching band of the caller's raster (replicate upsampling has no halo, src/decoder_utils.c:72-80).
+// (i)  A batch of independent frames: frame i goes to context i mod n.
+// Both run the pipelined host-pointer form of each context on its own thread; the first error wins.
+static int run_sharded(jpeggpu_ctx_t *const *ctxs, int nctx, const jpeggpu_frame_desc_t *d, uint32_t nframes,
+                       const jpeggpu_blocl16_t *const coef[3], const size_t cfs_in[3], const jpeggpu_qtable_t *const qt[4],
+                       uint8_t *out, size_t out_stride, size_t out_frame_stride, bool stripes) {
+   int rc = validate(d, qt); if (rc) return rc;
+   if (!ctxs || nctx < 1) return fail(JPEGGPU_ERR_INVALID_ARG, "no contexts");
+   for (int g = 0; g < nctx; g++) if (!ctxs[g]) return fail(JPEGGPU_ERR_INVALID_ARG, "ctxs[%d] is NULL", g);
+   if (!out) return fail(JPEGGPU_ERR_INVALID_ARG, "out is NULL");
+   for (int c = 0; c < d->nbcomp; c++) if (!coef || !coef[c]) return fail(JPEGGPU_ERR_INVALID_ARG, "coef[%d] is NULL", c);
+   const size_t row_bytes = jpeggpu_raster_row_bytes(d), rows = jpeggpu_raster_rows(d), band = (size_t)d->max_v * 8;
+   if (out_stride == 0) out_stride = row_bytes;
+   if (out_stride < row_bytes) return fail(JPEGGPU_ERR_INVALID_ARG, "out_stride %zu < row bytes %zu", out_stride, row_bytes);
+   if (out_frame_stride == 0) out_frame_stride = out_stride * rows;
+   size_t cfs[3] = { 0, 0, 0 }, row_in[3] = { 0, 0, 0 };
+   for (int c = 0; c < d->nbcomp; c++) {
+      cfs[c] = (cfs_in && cfs_in[c]) ? cfs_in[c] : jpeggpu_plane_blocks(d, c) * sizeof(jpeggpu_blocl16_t);
+      row_in[c] = (size_t)d->nbmcuH * d->comp[c].hs * d->comp[c].vs * sizeof(jpeggpu_blocl16_t);
+   }
+   std::vector<int> status((size_t)nctx, 0);
+   std::vector<std::string> text((size_t)nctx);
+   std::vector<std::thread> th;
+   for (int g = 0; g < nctx; g++)
+      th.emplace_back([&, g] {
+         int r = bind(ctxs[g]);
+         if (!r && stripes) {
+            const uint32_t m0 = (uint32_t)(((uint64_t)g * d->nbmcuV) / nctx), m1 = (uint32_t)(((uint64_t)(g + 1) * d->nbmcuV) / nctx);
+            if (m1 > m0) {
+               jpeggpu_frame_desc_t sd = *d;
+               sd.nbmcuV = m1 - m0;
+               const jpeggpu_blocl16_t *sc[3] = { nullptr, nullptr, nullptr };
+               for (int c = 0; c < d->nbcomp; c++) sc[c] = (const jpeggpu_blocl16_t *)((const char *)coef[c] + (size_t)m0 * row_in[c]);
+               r = run_host(ctxs[g], &sd, sc, qt, out + (size_t)m0 * band * out_stride, out_stride);
+            }
+         } else if (!r) {
+            for (uint32_t f = (uint32_t)g; f < nframes && !r; f += (uint32_t)nctx) {
+               const jpeggpu_blocl16_t *fc[3] = { nullptr, nullptr, nullptr };
+               for (int c = 0; c < d->nbcomp; c++) fc[c] = (const jpeggpu_blocl16_t *)((const char *)coef[c] + (size_t)f * cfs[c]);
+               r = run_host(ctxs[g], d, fc, qt, out + (size_t)f * out_frame_stride, out_stride);
+            }
+         }
+         status[(size_t)g] = r;
+         if (r) text[(size_t)g] = g_err;     // g_err is thread-local: carry the text back to the caller's thread
+      });
+   for (auto &t : th) t.join();
+   for (int g = 0; g < nctx; g++)
+      if (status[(size_t)g]) return fail(status[(size_t)g], "context %d (device %d): %s", g, ctxs[g]->device, text[(size_t)g].c_str());
+   return 0;
+}
+
+int jpeggpu_multi_backend_run(jpeggpu_ctx_t *const *ctxs, int nctx, const jpeggpu_frame_desc_t *d,
+                              const jpeggpu_blocl16_t *const coef[3], const jpeggpu_qtable_t *const qt[4], uint8_t *out, size_t out_stride) {
+   return run_sharded(ctxs, nctx, d, 1, coef, nullptr, qt, out, out_stride, 0, true);
+}
+
+int jpeggpu_multi_backend_run_batch(jpeggpu_ctx_t *const *ctxs, int nctx, const jpeggpu_frame_desc_t *d, uint32_t nframes,
+                                    const jpeggpu_blocl16_t *const coef[3], const size_t coef_frame_stride[3],
+                                    const jpeggpu_qtable_t *const qt[4], uint8_t *out, size_t out_stride, size_t out_frame_stride) {
+   return run_sharded(ctxs, nctx, d, nframes, coef, coef_frame_stride, qt, out, out_stride, out_frame_stride, false);
 }
 
 // ---- process-wide forms: the same on the default context -------------------------------------------

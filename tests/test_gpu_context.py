@@ -103,6 +103,30 @@ def test_context_option_is_per_context(gpu):
         assert np.array_equal(gpu.backend_run(gd, planes, QT), fast)  # the default context is untouched
 
 
+@pytest.mark.parametrize("nctx", [1, 2, 3, 8])
+def test_one_process_several_contexts_stripes_and_batches(gpu, nctx):
+    """jpeggpu_multi_backend_run / _batch: the shards of SURVEY 8e driven from ONE process, one host thread per context
+    (contexts on device 0 here; one per device on a multi-GPU host -- the same code path)."""
+    import torch
+    ndev = torch.cuda.device_count()
+    ctxs = [gpu.Context(i % ndev) for i in range(nctx)]
+    try:
+        for samp, (w, h) in ((((2, 2), (1, 1), (1, 1)), (1000, 333)), (((1, 1),) * 3, (517, 50)), (((1, 1),), (300, 17))):
+            d, planes, want = _frame(w, h, samp, 41)     # 17 rows of gray = 3 MCU rows: fewer stripes than contexts when nctx = 8
+            gd = helpers.to_gpu_desc(gpu, d)
+            assert np.array_equal(gpu.multi_backend_run(ctxs, gd, planes, QT), want), (nctx, samp)
+        d = helpers.oracle_desc(333, 70, ((2, 1), (1, 1), (1, 1)))
+        gd = helpers.to_gpu_desc(gpu, d)
+        nf = 5
+        nb = [helpers.plane_shape(d, c)[0] for c in range(3)]
+        host = [pyoracle.synth_blocks(nb[c] * nf, 45 + c) for c in range(3)]
+        got = gpu.multi_backend_run_batch(ctxs, gd, nf, host, QT)
+        for f in range(nf):
+            assert np.array_equal(got[f], orc.backend_run(d, [host[c][f * nb[c]:(f + 1) * nb[c]] for c in range(3)], QT)), (nctx, f)
+    finally:
+        [c.close() for c in ctxs]
+
+
 def test_ctx_errors(gpu):
     with pytest.raises(gpu.JpegGpuError) as e:
         gpu.Context(9999)
