@@ -251,7 +251,8 @@ int jpeggpu_idct_blocks(const jpeggpu_bloct16_t *in, jpeggpu_bloctu8_t *out, siz
 /* calc_coef's table [x][y][lambda][mu] as this library builds it (host only; cos/sqrt from libm). */
 void jpeggpu_idct_coef_table(float *out4096);
 /* all_option.idct_fast (src/options.c:76-79, a process-wide option in the reference as well):
- * 1 (default) = idct_opt, 0 = idct for every later jpeggpu_backend_run* / jpeggpu_jpeg_render call. */
+ * 1 (default) = idct_opt, 0 = idct for every later jpeggpu_backend_run* / jpeggpu_jpeg_render call on the default
+ * context, and the value contexts created later start with.  Atomic; a call reads it once; kept across jpeggpu_shutdown. */
 void jpeggpu_set_idct_fast(int fast);
 int  jpeggpu_get_idct_fast(void);
 /* ycc2rgb_pixel, src/ycc2rgb.c:18-22, over n pixels.                                           */

@@ -377,10 +377,11 @@ __device__ __forceinline__ const uint8_t *record_ptr(const BlockCtx &k, uint32_t
 // 6.4-6.7 TB/s, no slower than lane-coalesced loads and no LDS staging or extra barrier needed).
 //
 // Two prologues.  When every wave of the tile holds blocks of ONE component (p.wave_uniform: all component
-// boundaries are multiples of 64, e.g. 4:4:4 and 4:2:2 with 64 MCUs per tile) the component, its plane
-// geometry and its quantisation table are wave-uniform: they live in SGPRs, the table is 32 scalar loads from
-// the kernel arguments, and nothing is staged in LDS.  Otherwise (4:2:0: Cb and Cr share a wave) every lane
-// selects its component's fields with v_cndmask and the tables go through LDS.
+// boundaries are multiples of 64: 4:4:4, 4:2:2 and -- with its 384-block tiles, capi.cpp plan_backend -- 4:2:0 at
+// 64 MCUs per tile) the component, its plane geometry and its quantisation table are wave-uniform: they live in
+// SGPRs, the table is 32 scalar loads from the kernel arguments, and nothing is staged in LDS.  Otherwise (narrow
+// frames whose tile shrinks, sampling layouts such as 4:1:1 + 2x1 chroma, the JPEGGPU_NO_UNIFORM / _TILE_MCUS knobs)
+// every lane selects its component's fields with v_cndmask and the tables go through LDS.
 template <int HFC, int VFC, bool SLOW>   // chroma factors; 0 = generic path (any factors, any component)
 __device__ __forceinline__ void backend_body(const BackendParams &p) {
    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
