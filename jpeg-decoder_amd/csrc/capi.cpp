@@ -304,7 +304,7 @@ void plan_backend(const jpeggpu_frame_desc_t *d, const jpeggpu_qtable_t *const q
 
 int run_device(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, uint32_t nframes, const void *const d_coef[3], const size_t cfs[3],
                const jpeggpu_qtable_t *const qt[4], void *d_out, size_t out_stride, size_t out_frame_stride, hipStream_t s,
-               bool may_alloc = true) {
+               bool may_alloc = true, int idct_fast = -1) {   // idct_fast: -1 = read the context's option now, else the caller's snapshot
    BackendParams p; LaunchDims ld;
    plan_backend(d, qt, p, ld);
    const size_t row_bytes = jpeggpu_raster_row_bytes(d), rows = jpeggpu_raster_rows(d);
@@ -326,7 +326,7 @@ int run_device(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, uint32_t nfram
    if (const char *e = getenv("JPEGGPU_DIAG_PTR")) p.diag = (void *)strtoull(e, nullptr, 0);
 #endif
    if (nframes == 0) return 0;
-   if (!ctx->idct_fast.load()) {   // the option is read ONCE per call
+   if (!(idct_fast < 0 ? ctx->idct_fast.load() : idct_fast)) {   // the option is read ONCE per public call
       if (!may_alloc && !ctx->d_slow_coef.load())
          return fail(JPEGGPU_ERR_INVALID_ARG, "idct_fast == 0 needs its coefficient table on the device: make one ordinary call in this mode first");
       int rc = ensure_slow_coef(ctx, &p.slow_coef); if (rc) return rc;
@@ -356,6 +356,12 @@ int run_host(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, const jpeggpu_bl
    if (out_stride == 0) out_stride = row_bytes;
    if (out_stride < row_bytes) return fail(JPEGGPU_ERR_INVALID_ARG, "out_stride %zu < row bytes %zu", out_stride, row_bytes);
    std::lock_guard<std::mutex> lk(ctx->mu);
+   const int idct_fast = ctx->idct_fast.load();              // one snapshot for every stripe of this frame
+   // whatever way this function is left, nothing may still be copying from / into the caller's memory or the staging
+   struct Drain {
+      jpeggpu_ctx_s *c; bool armed = true;
+      ~Drain() { if (armed) { (void)hipStreamSynchronize(c->pipe[0]); (void)hipStreamSynchronize(c->pipe[1]); } }
+   } drain{ ctx };
    size_t plane_bytes[3] = { 0, 0, 0 }, off[3] = { 0, 0, 0 }, row_in[3] = { 0, 0, 0 }, in_bytes = 0, in_per_mcu_row = 0;
    for (int c = 0; c < d->nbcomp; c++) {
       plane_bytes[c] = jpeggpu_plane_blocks(d, c) * sizeof(jpeggpu_blocl16_t);
@@ -411,7 +417,7 @@ int run_host(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, const jpeggpu_bl
       jpeggpu_frame_desc_t sd = *d;
       sd.nbmcuV = n;
       uint8_t *d_band = (uint8_t *)ctx->d_out + (size_t)m0 * band * row_bytes;
-      rc = run_device(ctx, &sd, 1, dc, nullptr, qt, d_band, row_bytes, 0, s); if (rc) return rc;
+      rc = run_device(ctx, &sd, 1, dc, nullptr, qt, d_band, row_bytes, 0, s, true, idct_fast); if (rc) return rc;
       if (!out_pinned) HIP_TRY(hipMemcpyAsync(ctx->h_out[b], d_band, (size_t)n * band * row_bytes, hipMemcpyDeviceToHost, s));
       else if (out_stride == row_bytes) HIP_TRY(hipMemcpyAsync(out + (size_t)m0 * band * row_bytes, d_band, (size_t)n * band * row_bytes, hipMemcpyDeviceToHost, s));
       else HIP_TRY(hipMemcpy2DAsync(out + (size_t)m0 * band * out_stride, out_stride, d_band, row_bytes, row_bytes, (size_t)n * band, hipMemcpyDeviceToHost, s));
@@ -426,6 +432,7 @@ int run_host(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, const jpeggpu_bl
       if (!out_pinned) copy_out(k);
       queued[b] = false;
    }
+   drain.armed = false;                                       // both lanes have been waited for
    return 0;
 }
 
@@ -560,8 +567,7 @@ static int run_sharded(jpeggpu_ctx_t *const *ctxs, int nctx, const jpeggpu_frame
    std::vector<int> status((size_t)nctx, 0);
    std::vector<std::string> text((size_t)nctx);
    std::vector<std::thread> th;
-   for (int g = 0; g < nctx; g++)
-      th.emplace_back([&, g] {
+   auto shard = [&](int g) {
          int r = bind(ctxs[g]);
          if (!r && stripes) {
             const uint32_t m0 = (uint32_t)(((uint64_t)g * d->nbmcuV) / nctx), m1 = (uint32_t)(((uint64_t)(g + 1) * d->nbmcuV) / nctx);
@@ -581,7 +587,11 @@ static int run_sharded(jpeggpu_ctx_t *const *ctxs, int nctx, const jpeggpu_frame
          }
          status[(size_t)g] = r;
          if (r) text[(size_t)g] = g_err;     // g_err is thread-local: carry the text back to the caller's thread
-      });
+   };
+   for (int g = 0; g < nctx; g++) {
+      try { th.emplace_back(shard, g); }
+      catch (...) { shard(g); }              // no thread to be had: this shard runs on the caller's thread
+   }
    for (auto &t : th) t.join();
    for (int g = 0; g < nctx; g++)
       if (status[(size_t)g]) return fail(status[(size_t)g], "context %d (device %d): %s", g, ctxs[g]->device, text[(size_t)g].c_str());
