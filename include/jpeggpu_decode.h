@@ -82,9 +82,13 @@ int  jpeggpu_jpeg_decode_scan(jpeggpu_jpeg_t *j);
 int  jpeggpu_jpeg_next_header(jpeggpu_jpeg_t *j);
 
 /* The pixel back end over the current planes (GPU): host raster out, layout of
- * jpeggpu_backend_run.  Planes stay resident on the device between calls; only components
- * touched by scans since the previous render are uploaded again.                                 */
+ * jpeggpu_backend_run.  Planes stay resident on the device between calls; only what the scans since
+ * the previous render changed is uploaded again: the plane of a component an AC (or baseline) scan
+ * touched, and for a component that only DC scans touched (src/progressive.c:98-126) just the dirty
+ * spectral band -- coefficient 0 of every block, 2 of each 128 bytes -- which a small kernel puts in place. */
 int  jpeggpu_jpeg_render(jpeggpu_jpeg_t *j, uint8_t *out, size_t out_stride);
+/* Host-to-device bytes this handle has queued so far (a measure of the hand-off, for tests and tuning). */
+size_t jpeggpu_jpeg_uploaded_bytes(const jpeggpu_jpeg_t *j);
 
 /* Output stage: "P5\n"|"P6\n", "%d %d\n", "255\n" (src/baseline.c:121-130, src/progressive.c:241-244)
  * followed by ALL raster rows, padded ones included (src/decoder_utils.c:51,68).                 */

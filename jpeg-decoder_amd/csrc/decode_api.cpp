@@ -19,6 +19,7 @@
 #include <string>
 
 #include "../../include/jpeggpu_decode.h"
+#include "kernels.h"
 #include "frontend.hpp"
 
 namespace {
@@ -48,6 +49,9 @@ struct jpeggpu_jpeg {
    hipStream_t stream = nullptr;
    hipEvent_t uploaded = nullptr;
    void *d_plane[3] = { nullptr, nullptr, nullptr };
+   void *d_pack[3] = { nullptr, nullptr, nullptr };   // device side of Decoder::dc_pack (progressive files)
+   bool d_zeroed[3] = { false, false, false };        // the device plane has been initialised (uploaded or cleared)
+   size_t uploaded_bytes = 0;                         // host-to-device bytes queued so far (jpeggpu_jpeg_uploaded_bytes)
    void *d_out = nullptr;
    uint8_t *h_out = nullptr;      // pinned raster
    size_t out_bytes = 0;
@@ -92,6 +96,12 @@ int alloc_planes(jpeggpu_jpeg *j) {
       if (!p) return dfail(JPEGGPU_ERR_IO, "allocation de %zu octets impossible", bytes);
       memset(p, 0, bytes);
       d.plane[c] = (int16_t *)p;
+      // progressive files: DC scans also leave their coefficients packed (2 bytes per block) for the per-scan hand-off
+      if (j->pinned && d.num_sof == 2 && j->plane_bytes[c] >= 128) {
+         void *q = nullptr;
+         if (hipHostMalloc(&q, j->plane_bytes[c] / 64, hipHostMallocDefault) == hipSuccess) { memset(q, 0, j->plane_bytes[c] / 64); d.dc_pack[c] = (int16_t *)q; }
+         else (void)hipGetLastError();   // no packed side: whole planes are uploaded
+      }
    }
    return 0;
 }
@@ -100,6 +110,8 @@ void free_all(jpeggpu_jpeg *j) {
    // every member is released on its own: a render that failed half-way through its allocations leaves some set
    if (j->stream) (void)hipStreamSynchronize(j->stream);
    for (int c = 0; c < 3; c++) if (j->d_plane[c]) (void)hipFree(j->d_plane[c]);
+   for (int c = 0; c < 3; c++) if (j->d_pack[c]) (void)hipFree(j->d_pack[c]);
+   for (int c = 0; c < 3; c++) if (j->d.dc_pack[c]) (void)hipHostFree(j->d.dc_pack[c]);
    if (j->d_out) (void)hipFree(j->d_out);
    if (j->h_out) (void)hipHostFree(j->h_out);
    if (j->uploaded) (void)hipEventDestroy(j->uploaded);
@@ -149,17 +161,34 @@ int render_begin(jpeggpu_jpeg *j) {
       if (!j->uploaded) HIP_TRYD(hipEventCreateWithFlags(&j->uploaded, hipEventDisableTiming));
       for (int c = 0; c < d.nbcomp; c++) {
          if (!j->d_plane[c]) HIP_TRYD(hipMalloc(&j->d_plane[c], j->plane_bytes[c] ? j->plane_bytes[c] : 128));
+         if (d.dc_pack[c] && !j->d_pack[c]) HIP_TRYD(hipMalloc(&j->d_pack[c], j->plane_bytes[c] / 64));
          d.dirty[c] = true;
+         if (d.dirty_kind[c] == jpegfe::Decoder::kClean) d.dirty_kind[c] = jpegfe::Decoder::kWhole;   // nothing decoded yet: the (zero) plane as it is
       }
       j->out_bytes = jpeggpu_raster_rows(&desc) * jpeggpu_raster_row_bytes(&desc);
       if (!j->d_out) HIP_TRYD(hipMalloc(&j->d_out, j->out_bytes ? j->out_bytes : 16));
       if (!j->h_out) HIP_TRYD(hipHostMalloc((void **)&j->h_out, j->out_bytes ? j->out_bytes : 16, hipHostMallocDefault));
       j->gpu = true;
    }
+   // Per-scan hand-off (src/progressive.c:209-331 runs the whole back end after every scan): a component that only DC
+   // scans touched since its last upload sends the dirty spectral band -- coefficient 0, 2 of every 128 bytes -- and a
+   // small kernel puts it in place; the first time round the device plane is cleared instead of uploaded (everything
+   // but coefficient 0 is still zero on the host as well).  Anything else sends the component's plane.
    for (int c = 0; c < d.nbcomp; c++)
       if (d.dirty[c] && j->plane_bytes[c]) {
-         HIP_TRYD(hipMemcpyAsync(j->d_plane[c], d.plane[c], j->plane_bytes[c], hipMemcpyHostToDevice, j->stream));
+         const size_t nblocks = j->plane_bytes[c] / 128;
+         if (d.dirty_kind[c] == jpegfe::Decoder::kDcOnly && j->d_pack[c] && d.dc_pack[c]) {
+            if (!j->d_zeroed[c]) HIP_TRYD(hipMemsetAsync(j->d_plane[c], 0, j->plane_bytes[c], j->stream));
+            HIP_TRYD(hipMemcpyAsync(j->d_pack[c], d.dc_pack[c], nblocks * 2, hipMemcpyHostToDevice, j->stream));
+            HIP_TRYD(jpeggpu_k::launch_scatter_dc(j->d_plane[c], j->d_pack[c], nblocks, j->stream));
+            j->uploaded_bytes += nblocks * 2;
+         } else {
+            HIP_TRYD(hipMemcpyAsync(j->d_plane[c], d.plane[c], j->plane_bytes[c], hipMemcpyHostToDevice, j->stream));
+            j->uploaded_bytes += j->plane_bytes[c];
+         }
+         j->d_zeroed[c] = true;
          d.dirty[c] = false;
+         d.dirty_kind[c] = jpegfe::Decoder::kClean;
       }
    HIP_TRYD(hipEventRecord(j->uploaded, j->stream));
    rc = jpeggpu_backend_run_device(&desc, (const void *const *)j->d_plane, qt, j->d_out, 0, j->stream);
@@ -246,6 +275,7 @@ int jpeggpu_jpeg_open_file(const char *path, jpeggpu_jpeg_t **out) {
 }
 
 void jpeggpu_jpeg_close(jpeggpu_jpeg_t *j) { if (j) free_all(j); }
+size_t jpeggpu_jpeg_uploaded_bytes(const jpeggpu_jpeg_t *j) { return j ? j->uploaded_bytes : 0; }
 
 int jpeggpu_jpeg_frame_desc(const jpeggpu_jpeg_t *j, jpeggpu_frame_desc_t *desc) {
    if (!j || !desc) return JPEGGPU_ERR_INVALID_ARG;
@@ -392,7 +422,7 @@ int jpeggpu_jpeg2ppm_timed(const char *filepath, const char *outfile, int *nb_im
       { Lap lap(tm.vld_s); drc = report(j, j->d.decode_scan()); }
       std::string derr = j->d.err;
       size_t rows = drc ? (size_t)j->d.mcu_rows_done * desc.max_v * 8 : jpeggpu_raster_rows(&desc);
-      if (drc) for (int c = 0; c < desc.nbcomp; c++) j->d.dirty[c] = true;
+      if (drc) for (int c = 0; c < desc.nbcomp; c++) { j->d.dirty[c] = true; j->d.dirty_kind[c] = jpegfe::Decoder::kWhole; }
       rc = 0;
       if (rows && rb) { Lap lap(tm.gpu_wait_s); rc = render_begin(j); if (!rc) rc = render_end(j); }
       if (!rc) {

@@ -634,7 +634,7 @@ int Decoder::scan_baseline(BitReader &br) {
       }
       mcu_rows_done = my + 1;
    }
-   for (int k = 0; k < nsc; k++) dirty[scan_c[k]] = true;
+   for (int k = 0; k < nsc; k++) { dirty[scan_c[k]] = true; dirty_kind[scan_c[k]] = kWhole; }
    return 0;
 }
 
@@ -671,9 +671,13 @@ int Decoder::scan_progressive_dc(BitReader &br) {
                      blk[0] = (int16_t)(blk[0] + pred[c]);
                   }
                   pred[c] = blk[0];
+                  if (dc_pack[c]) dc_pack[c][((size_t)my * ci.vs + by) * nbH + (size_t)mx * ci.hs + bx] = blk[0];
                }
          }
-   for (int k = 0; k < nsc; k++) dirty[scan_c[k]] = true;
+   for (int k = 0; k < nsc; k++) {
+      dirty[scan_c[k]] = true;
+      if (dirty_kind[scan_c[k]] < kDcOnly) dirty_kind[scan_c[k]] = kDcOnly;
+   }
    return 0;
 }
 
@@ -714,6 +718,7 @@ int Decoder::scan_progressive_ac(BitReader &br) {
          }
       }
    dirty[c] = true;
+   dirty_kind[c] = kWhole;
    return 0;
 }
 

@@ -62,6 +62,12 @@ struct Decoder {
    // decoder state
    int16_t *plane[3] = { nullptr, nullptr, nullptr };   // zeroed full-frame planes, owned by the caller (pinned when a GPU is present)
    bool dirty[3] = { false, false, false };
+   // What the scans since the last upload changed in a component's plane: only coefficient 0 of its blocks (DC scans,
+   // src/progressive.c:98-126) or anything.  With dc_pack[c] attached, DC scans also leave every block's coefficient 0 in
+   // dc_pack[c][block index] -- the "dirty spectral band" a per-scan hand-off uploads instead of the whole plane.
+   enum : uint8_t { kClean = 0, kDcOnly = 1, kWhole = 2 };
+   uint8_t dirty_kind[3] = { kClean, kClean, kClean };
+   int16_t *dc_pack[3] = { nullptr, nullptr, nullptr };
    unsigned scans_decoded = 0;
    bool dequant_on_store = false;     // baseline only: store coef * qtable (int16 wrap) like decode_bloc_baseline's iquant (src/baseline.c:66)
    uint32_t mcu_rows_done = 0;        // complete MCU rows of the last baseline scan (partial output on error)

@@ -59,6 +59,7 @@ hipError_t static_scratch(int device, void **ptr);
 // stage-level kernels (device pointers)
 hipError_t launch_iquant(void *d_blocks, size_t n, int s_start, int s_end, const uint32_t qt_packed[32], hipStream_t s);
 hipError_t launch_izz(const void *d_in, void *d_out, size_t n, hipStream_t s);
+hipError_t launch_scatter_dc(void *d_blocks, const void *d_pack, size_t n, hipStream_t s);   // blocks[b].data[0] = pack[b]
 hipError_t launch_idct(const void *d_in, void *d_out, size_t n, hipStream_t s);
 hipError_t launch_idct_slow(const void *d_in, void *d_out, size_t n, const float *d_coef, hipStream_t s);
 hipError_t launch_ycc2rgb(const uint8_t *d_y, const uint8_t *d_cb, const uint8_t *d_cr, uint8_t *d_rgb, size_t n, hipStream_t s);

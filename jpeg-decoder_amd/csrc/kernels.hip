@@ -616,6 +616,12 @@ __global__ void iquant_kernel(int16_t *blocks, size_t n, int s0, int s1, QtArg q
    blocks[i] = (int16_t)(short)((int)blocks[i] * (int)qq);
 }
 
+// Progressive per-scan hand-off: a DC scan changes only coefficient 0 of every block.  pack[b] -> blocks[b].data[0].
+__global__ void scatter_dc_kernel(int16_t *blocks, const int16_t *pack, size_t n) {
+   const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (b < n) blocks[b * 64] = pack[b];
+}
+
 __global__ void izz_kernel(const int16_t *in, int16_t *out, size_t n) {
    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // one coefficient per thread
    if (i >= n * 64) return;
@@ -688,6 +694,12 @@ hipError_t launch_iquant(void *d_blocks, size_t n, int s_start, int s_end, const
    QtArg q; for (int i = 0; i < 32; i++) q.w[i] = qt_packed[i];
    (void)hipGetLastError();
    hipLaunchKernelGGL(iquant_kernel, dim3(nblocks(n * 64, 256)), dim3(256), 0, s, static_cast<int16_t *>(d_blocks), n, s_start, s_end, q);
+   return hipGetLastError();
+}
+hipError_t launch_scatter_dc(void *d_blocks, const void *d_pack, size_t n, hipStream_t s) {
+   if (n == 0) return hipSuccess;
+   (void)hipGetLastError();
+   hipLaunchKernelGGL(scatter_dc_kernel, dim3(nblocks(n, 256)), dim3(256), 0, s, static_cast<int16_t *>(d_blocks), static_cast<const int16_t *>(d_pack), n);
    return hipGetLastError();
 }
 hipError_t launch_izz(const void *d_in, void *d_out, size_t n, hipStream_t s) {

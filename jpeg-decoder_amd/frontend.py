@@ -43,6 +43,8 @@ lib.jpeggpu_jpeg_comment.restype = C.c_char_p
 lib.jpeggpu_jpeg_decode_scan.argtypes = [_vp]
 lib.jpeggpu_jpeg_next_header.argtypes = [_vp]
 lib.jpeggpu_jpeg_render.argtypes = [_vp, _vp, _sz]
+lib.jpeggpu_jpeg_uploaded_bytes.argtypes = [_vp]
+lib.jpeggpu_jpeg_uploaded_bytes.restype = _sz
 lib.jpeggpu_write_pnm.argtypes = [C.c_char_p, C.POINTER(B.FrameDesc), _vp, _sz]
 lib.jpeggpu_write_pnm_rows.argtypes = [C.c_char_p, C.POINTER(B.FrameDesc), _vp, _sz, _sz]
 lib.jpeggpu_out_file_name.argtypes = [C.c_char_p, C.c_char_p, C.c_uint8, C.c_uint8, C.c_char_p, _sz]
@@ -115,6 +117,11 @@ class Jpeg:
 
     def next_header(self):
         B._check(lib.jpeggpu_jpeg_next_header(self._h))
+
+    @property
+    def uploaded_bytes(self):
+        """Host-to-device bytes queued by the renders of this file so far."""
+        return lib.jpeggpu_jpeg_uploaded_bytes(self._h)
 
     def render(self):
         """GPU back end over the current planes -> (rows, row_bytes) uint8 raster."""

@@ -173,3 +173,30 @@ def test_integration_binding_slow_idct_option(gpu, tmp_path):
     r = subprocess.run([exe, "-f", "-o", str(out / "x.pnm"), os.path.join(JDIR, name)], capture_output=True, timeout=110)
     assert r.returncode == 0, r.stderr[-300:]
     _check_outputs(out, e)
+
+
+def test_per_scan_hand_off_uploads_the_dirty_band(gpu):
+    """Progressive per-scan hand-off: a DC scan uploads coefficient 0 of every block (2 of each 128 bytes),
+    an AC scan the plane of its one component; every scan's image equals the reference's (expect.json)."""
+    from jpeg_decoder_amd import frontend as F
+    name = "c4_prog422_160x120.jpg"
+    j = F.Jpeg(open(os.path.join(JDIR, name), "rb").read())
+    d = j.desc
+    plane_bytes = [gpu.plane_blocks(d, c) * 128 for c in range(3)]
+    imgs, ups, scans = [], [], []
+    while not j.eoi:
+        j.decode_scan()
+        scans.append((j.scan.ss, j.scan.se, j.scan.nb_scan_comp))
+        before = j.uploaded_bytes
+        imgs.append(F.pnm_header(d) + j.render().tobytes())
+        ups.append(j.uploaded_bytes - before)
+        if j.eoi:
+            break
+        j.next_header()
+    assert [hashlib.sha256(b).hexdigest() for b in imgs] == expected_images(EXPECT[name])
+    for (ss, se, nbc), up in zip(scans, ups):
+        if se == 0:      # DC scan over all three components: first one and its refinement
+            assert nbc == 3 and up == sum(plane_bytes) // 64, (ss, se, up)
+        else:            # AC scan: one component's whole plane
+            assert up in plane_bytes, (ss, se, up)
+    assert sum(1 for s in scans if s[1] == 0) >= 2      # Pillow's script has a DC refinement scan
