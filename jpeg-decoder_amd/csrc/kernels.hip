@@ -425,7 +425,8 @@ __device__ __forceinline__ void backend_body(const BackendParams &p) {
       const uint32_t hsh = p.hs_shift[c];
       const uint32_t j = bxl >> hsh;                        // MCU of the tile this block belongs to
       const bool r2 = j >= geo.wrapj && j < geo.nvalid;
-      uint32_t col = r2 ? bxl - (geo.wrapj << hsh) : (geo.c0 << hsh) + bxl;
+      const uint32_t col0 = p.linear ? (geo.c0 << hsh) : tile * bw;   // first block column of the tile (hs is a power of two under linear tiling only)
+      uint32_t col = r2 ? bxl - (geo.wrapj << hsh) : col0 + bxl;
       col = min(col, nbH - 1);                              // lanes right of the plane / past the frame's last MCU read a valid block: never stored
       const uint8_t *base = static_cast<const uint8_t *>(p.coef[c]) + (size_t)frame * p.coef_frame_stride[c] +
                             (size_t)m * vs * nbH * 128;      // uniform; two MCU rows of a plane are < 2^32 bytes

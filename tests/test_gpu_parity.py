@@ -376,3 +376,44 @@ def test_bench_line_contract(gpu):
     assert "workload" in res["config"] and res["value"] > 0
     rf = res["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+
+
+def test_randomised_geometries_vs_oracle(gpu):
+    """700 random frames -- every sampling layout the writers accept, widths that cut MCUs, tiles that wrap (linear tiling),
+    batches, padded rows and frame strides, both iquant modes -- through the device-pointer entry, byte for byte vs the oracle."""
+    import torch
+    rng = np.random.default_rng(20251111)
+    layouts = SAMPLINGS + [((2, 1), (2, 1), (1, 1)), ((1, 1), (1, 1), (1, 1)), ((2, 2), (1, 2), (1, 2)), ((4, 4), (2, 2), (2, 2)), ((3, 1), (1, 1), (1, 1))]
+    for case in range(700):
+        samp = layouts[int(rng.integers(len(layouts)))]
+        mw, mh = max(s[0] for s in samp) * 8, max(s[1] for s in samp) * 8
+        nmh = int(rng.choice([1, 2, 7, 31, 63, 64, 65, 66, 100, 127, 129, 200, 257]))
+        w = nmh * mw - int(rng.integers(0, mw))
+        h = int(rng.integers(1, 4)) * mh - int(rng.integers(0, mh))
+        if w < 1 or h < 1 or w > 65535:
+            continue
+        aq = bool(rng.integers(2))
+        d = helpers.oracle_desc(w, h, samp, apply_iquant=aq)
+        gd = helpers.to_gpu_desc(gpu, d)
+        nf = int(rng.choice([1, 1, 2, 3]))
+        nc = len(samp)
+        nb = [helpers.plane_shape(d, c)[0] for c in range(nc)]
+        pad_blocks = int(rng.integers(0, 3))                       # frames need not be packed back to back
+        host = [pyoracle.synth_blocks((nb[c] + pad_blocks) * nf, 7000 + 3 * case + c, 0, int(rng.integers(0, 2))) for c in range(nc)]
+        dev = [torch.from_numpy(a).cuda() for a in host]
+        rows, rb = gpu.raster_rows(gd), gpu.raster_row_bytes(gd)
+        stride = rb + int(rng.choice([0, 0, 1, 5, 64]))
+        fstride = stride * rows + int(rng.choice([0, 0, 3, 128]))
+        out = torch.full((nf * fstride + 64,), 0xA5, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        gpu.backend_run_batch_device(gd, nf, [t.data_ptr() for t in dev], [(nb[c] + pad_blocks) * 128 for c in range(nc)], QT,
+                                     out.data_ptr(), stride, fstride)
+        gpu.synchronize()
+        got = out.cpu().numpy()
+        for f in range(nf):
+            planes = [host[c][f * (nb[c] + pad_blocks):f * (nb[c] + pad_blocks) + nb[c]] for c in range(nc)]
+            want = orc.backend_run(d, planes, QT)
+            fr = got[f * fstride:f * fstride + rows * stride].reshape(rows, stride)
+            assert np.array_equal(fr[:, :rb], want), (case, samp, w, h, aq, nf, f, stride)
+            assert np.all(fr[:, rb:] == 0xA5), (case, "row padding touched")
+        assert np.all(got[nf * fstride:] == 0xA5), (case, "bytes past the last frame touched")
