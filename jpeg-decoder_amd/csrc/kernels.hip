@@ -504,6 +504,7 @@ __device__ __forceinline__ void backend_body(const BackendParams &p) {
       if constexpr (SLOW) transform_block_slow(zw, plane, pitch, p.slow_coef);
       else transform_block(zw, plane, pitch);
    }
+
 #if defined(JM_DIAG_STAMP)
    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
    const long long ts2 = __builtin_amdgcn_s_memtime();
