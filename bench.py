@@ -164,7 +164,8 @@ def end_to_end(jg, np, d, qt, w, h, reps=3):
     rows, rb = jg.raster_rows(d), jg.raster_row_bytes(d)
     nbytes = sum(nb) * 128 + rows * rb
     planes = [synth.synth_blocks(nb[c], 0xE2E + c) for c in range(d.nbcomp)]
-    res = {"frame_bytes_in_plus_out": int(nbytes), "pcie_spec_GBps": 63.0}
+    res = {"frame_bytes_in_plus_out": int(nbytes), "pcie_spec_GBps_per_direction": 63.0,
+           "link_measured": "57 GB/s up, 57 GB/s down, 85 GB/s both at once (profiles/r02_probe_pcie.txt); GBps below = (in + out) / time"}
     out = np.empty((rows, rb), dtype=np.uint8)
     best = None
     for _ in range(reps + 1):

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -27,8 +28,8 @@ using namespace jpeggpu_k;
 struct jpeggpu_ctx_s {
    int device = -1;
    hipStream_t stream = nullptr;                 // default stream of the context (device-pointer forms with hip_stream == NULL)
-   hipStream_t pipe[2] = { nullptr, nullptr };   // the two lanes of the host-pointer pipeline
-   hipEvent_t pipe_done[2] = { nullptr, nullptr };
+   hipStream_t pipe[2] = { nullptr, nullptr };   // host-pointer pipeline: [0] uploads, [1] kernels and downloads
+   hipEvent_t up_done[2] = { nullptr, nullptr }, pipe_done[2] = { nullptr, nullptr };   // per stripe parity: uploaded / downloaded
    std::mutex mu;                                // host-pointer and stage-level entries: they share the staging below
    void *d_in = nullptr;  size_t d_in_cap = 0;
    void *d_out = nullptr; size_t d_out_cap = 0;
@@ -104,9 +105,14 @@ int ctx_new(int device, jpeggpu_ctx_s **out) {
    for (int i = 0; i < 2 && rc == hipSuccess; i++) {
       rc = hipStreamCreateWithFlags(&c->pipe[i], hipStreamNonBlocking);
       if (rc == hipSuccess) rc = hipEventCreateWithFlags(&c->pipe_done[i], hipEventDisableTiming);
+      if (rc == hipSuccess) rc = hipEventCreateWithFlags(&c->up_done[i], hipEventDisableTiming);
    }
    if (rc != hipSuccess) {
-      for (int i = 0; i < 2; i++) { if (c->pipe_done[i]) (void)hipEventDestroy(c->pipe_done[i]); if (c->pipe[i]) (void)hipStreamDestroy(c->pipe[i]); }
+      for (int i = 0; i < 2; i++) {
+         if (c->pipe_done[i]) (void)hipEventDestroy(c->pipe_done[i]);
+         if (c->up_done[i]) (void)hipEventDestroy(c->up_done[i]);
+         if (c->pipe[i]) (void)hipStreamDestroy(c->pipe[i]);
+      }
       if (c->stream) (void)hipStreamDestroy(c->stream);
       delete c;
       return fail(JPEGGPU_ERR_HIP, "stream/event creation on device %d: %s", device, hipGetErrorString(rc));
@@ -131,6 +137,7 @@ void ctx_delete(jpeggpu_ctx_s *c) {
       if (c->h_in[i]) (void)hipHostFree(c->h_in[i]);
       if (c->h_out[i]) (void)hipHostFree(c->h_out[i]);
       (void)hipEventDestroy(c->pipe_done[i]);
+      (void)hipEventDestroy(c->up_done[i]);
       (void)hipStreamDestroy(c->pipe[i]);
    }
    if (c->d_in) (void)hipFree(c->d_in);
@@ -345,11 +352,14 @@ bool is_pinned_host(const void *p) {
 }
 
 // The host-pointer form.  The frame is cut into stripes of whole MCU rows (a stripe is a frame of its own to the
-// kernel: replicate upsampling has no halo, src/decoder_utils.c:72-80) that alternate between two streams, so the
-// upload of stripe k+1, the kernel of stripe k and the download of stripe k-1 overlap.  Caller memory that is already
-// pinned (hipHostMalloc, hipHostRegister / jpeggpu_host_register) is read and written by the DMA engines in place;
-// pageable memory (the reference's malloc'ed buffers, src/progressive.c:73-84) goes through two pinned stripe
-// buffers, filled and emptied by this thread while the other stripe is in flight.
+// kernel: replicate upsampling has no halo, src/decoder_utils.c:72-80).  The link to the host is full duplex
+// (profiles/r02_probe_pcie.txt: 57 GB/s up and 57 GB/s down at the same time), so the uploads of all stripes queue
+// back to back on one stream and nothing else ever sits between them; a second stream takes, per stripe, the wait for
+// that stripe's upload, its kernel and its download.  Upload of stripe k+1, kernel of stripe k and download of stripe
+// k-1 overlap, and the call costs the upload time plus one stripe's kernel and download.  Caller memory that is
+// already pinned (jpeggpu_host_alloc, hipHostMalloc, jpeggpu_host_register) is read and written by the DMA engines in
+// place; pageable memory (the reference's malloc'ed buffers, src/progressive.c:73-84) goes through two pinned stripe
+// buffers per direction, filled and emptied by this thread while the other stripe is in flight.
 int run_host(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, const jpeggpu_blocl16_t *const coef[3], const jpeggpu_qtable_t *const qt[4],
              uint8_t *out, size_t out_stride) {
    const size_t row_bytes = jpeggpu_raster_row_bytes(d), rows = jpeggpu_raster_rows(d);
@@ -357,6 +367,7 @@ int run_host(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, const jpeggpu_bl
    if (out_stride < row_bytes) return fail(JPEGGPU_ERR_INVALID_ARG, "out_stride %zu < row bytes %zu", out_stride, row_bytes);
    std::lock_guard<std::mutex> lk(ctx->mu);
    const int idct_fast = ctx->idct_fast.load();              // one snapshot for every stripe of this frame
+   hipStream_t s_up = ctx->pipe[0], s_down = ctx->pipe[1];
    // whatever way this function is left, nothing may still be copying from / into the caller's memory or the staging
    struct Drain {
       jpeggpu_ctx_s *c; bool armed = true;
@@ -375,8 +386,9 @@ int run_host(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, const jpeggpu_bl
    bool in_pinned = true;
    for (int c = 0; c < d->nbcomp; c++) in_pinned = in_pinned && is_pinned_host(coef[c]);
    const bool out_pinned = is_pinned_host(out);
-   // stripe height: ~8 MiB of coefficients, at least one MCU row, at most the frame
-   const size_t target = tuning().stripe_bytes ? tuning().stripe_bytes : ((size_t)8 << 20);
+   // stripe height: ~16 MiB of coefficients when the DMA engines work in place, ~8 MiB when a host thread stages
+   // (tools/sweep_stripe.py, profiles/r02_sweep_stripe.txt), at least one MCU row, at most the frame
+   const size_t target = tuning().stripe_bytes ? tuning().stripe_bytes : ((size_t)(in_pinned && out_pinned ? 16 : 8) << 20);
    uint32_t srows = (uint32_t)(target / (in_per_mcu_row ? in_per_mcu_row : 1));
    if (srows < 1) srows = 1;
    if (srows > d->nbmcuV) srows = d->nbmcuV;
@@ -391,16 +403,37 @@ int run_host(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, const jpeggpu_bl
       if (out_stride == row_bytes) memcpy(dst, src, (size_t)n * band * row_bytes);
       else for (size_t r = 0; r < (size_t)n * band; r++) memcpy(dst + r * out_stride, src + r * row_bytes, row_bytes);
    };
-   bool queued[2] = { false, false };
+   // Pageable output of some size: a second host thread empties the download staging while this one fills the upload
+   // staging (one thread copies ~29 GB/s, profiles/r02_sweep_stripe.txt, and would otherwise move in + out = 1.5x
+   // the frame's coefficients by itself).  It lives for this call only and is joined on every way out.
+   struct OutCopier {
+      std::thread th;
+      std::atomic<uint32_t> enqueued{ 0 }, copied{ 0 };        // stripes whose download is queued / is in the caller's rows
+      std::atomic<int> err{ 0 };
+      std::atomic<bool> stop{ false };
+      ~OutCopier() { stop.store(true); if (th.joinable()) th.join(); }
+   } oc;
+   bool helper = !out_pinned && nstripes >= 3 && out_bytes >= ((size_t)16 << 20);
+   if (helper) {
+      try {
+         oc.th = std::thread([&, nstripes] {
+            if (hipSetDevice(ctx->device) != hipSuccess) { oc.err.store((int)hipErrorInvalidDevice); return; }
+            for (uint32_t k = 0; k < nstripes; k++) {
+               while (oc.enqueued.load(std::memory_order_acquire) <= k) { if (oc.stop.load()) return; std::this_thread::yield(); }
+               hipError_t e = hipEventSynchronize(ctx->pipe_done[k & 1]);
+               if (e != hipSuccess) { oc.err.store((int)e); return; }
+               copy_out(k);
+               oc.copied.store(k + 1, std::memory_order_release);
+            }
+         });
+      } catch (const std::system_error &) { helper = false; }    // no thread to be had: this thread copies, as for small frames
+   }
+   // events are used in rings of two: a hipStreamWaitEvent refers to the record that preceded it, recording the event
+   // again for stripe k+2 does not disturb it
    for (uint32_t k = 0; k < nstripes; k++) {
       const int b = (int)(k & 1);
-      hipStream_t s = ctx->pipe[b];
       const uint32_t m0 = k * srows, n = (m0 + srows <= d->nbmcuV ? srows : d->nbmcuV - m0);
-      if (queued[b] && (!in_pinned || !out_pinned)) {   // stripe k-2 used the same staging buffers
-         HIP_TRY(hipEventSynchronize(ctx->pipe_done[b]));
-         if (!out_pinned) copy_out(k - 2);
-         queued[b] = false;
-      }
+      if (!in_pinned && k >= 2) HIP_TRY(hipEventSynchronize(ctx->up_done[b]));   // stripe k-2 has left this staging buffer
       const void *dc[3] = { nullptr, nullptr, nullptr };
       size_t hoff = 0;
       for (int c = 0; c < d->nbcomp; c++) {
@@ -411,28 +444,45 @@ int run_host(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, const jpeggpu_bl
             src = (const char *)ctx->h_in[b] + hoff;
             hoff += (size_t)n * row_in[c];
          }
-         HIP_TRY(hipMemcpyAsync(dst, src, (size_t)n * row_in[c], hipMemcpyHostToDevice, s));
+         HIP_TRY(hipMemcpyAsync(dst, src, (size_t)n * row_in[c], hipMemcpyHostToDevice, s_up));
          dc[c] = dst;
       }
+      HIP_TRY(hipEventRecord(ctx->up_done[b], s_up));
+      if (!out_pinned && k >= 2) {                               // stripe k-2 sits in the staging buffer stripe k downloads into
+         if (helper) {
+            while (oc.copied.load(std::memory_order_acquire) < k - 1) {
+               if (oc.err.load()) return fail(JPEGGPU_ERR_HIP, "download of a stripe: %s", hipGetErrorString((hipError_t)oc.err.load()));
+               std::this_thread::yield();
+            }
+         } else {
+            HIP_TRY(hipEventSynchronize(ctx->pipe_done[b]));
+            copy_out(k - 2);
+         }
+      }
+      HIP_TRY(hipStreamWaitEvent(s_down, ctx->up_done[b], 0));
       jpeggpu_frame_desc_t sd = *d;
       sd.nbmcuV = n;
       uint8_t *d_band = (uint8_t *)ctx->d_out + (size_t)m0 * band * row_bytes;
-      rc = run_device(ctx, &sd, 1, dc, nullptr, qt, d_band, row_bytes, 0, s, true, idct_fast); if (rc) return rc;
-      if (!out_pinned) HIP_TRY(hipMemcpyAsync(ctx->h_out[b], d_band, (size_t)n * band * row_bytes, hipMemcpyDeviceToHost, s));
-      else if (out_stride == row_bytes) HIP_TRY(hipMemcpyAsync(out + (size_t)m0 * band * row_bytes, d_band, (size_t)n * band * row_bytes, hipMemcpyDeviceToHost, s));
-      else HIP_TRY(hipMemcpy2DAsync(out + (size_t)m0 * band * out_stride, out_stride, d_band, row_bytes, row_bytes, (size_t)n * band, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipEventRecord(ctx->pipe_done[b], s));
-      queued[b] = true;
+      rc = run_device(ctx, &sd, 1, dc, nullptr, qt, d_band, row_bytes, 0, s_down, true, idct_fast); if (rc) return rc;
+      if (!out_pinned) HIP_TRY(hipMemcpyAsync(ctx->h_out[b], d_band, (size_t)n * band * row_bytes, hipMemcpyDeviceToHost, s_down));
+      else if (out_stride == row_bytes) HIP_TRY(hipMemcpyAsync(out + (size_t)m0 * band * row_bytes, d_band, (size_t)n * band * row_bytes, hipMemcpyDeviceToHost, s_down));
+      else HIP_TRY(hipMemcpy2DAsync(out + (size_t)m0 * band * out_stride, out_stride, d_band, row_bytes, row_bytes, (size_t)n * band, hipMemcpyDeviceToHost, s_down));
+      HIP_TRY(hipEventRecord(ctx->pipe_done[b], s_down));
+      oc.enqueued.store(k + 1, std::memory_order_release);
    }
-   // drain, oldest stripe first
-   for (uint32_t k = (nstripes >= 2 ? nstripes - 2 : 0); k < nstripes; k++) {
-      const int b = (int)(k & 1);
-      if (!queued[b]) continue;
-      HIP_TRY(hipEventSynchronize(ctx->pipe_done[b]));
-      if (!out_pinned) copy_out(k);
-      queued[b] = false;
+   if (helper) {
+      oc.th.join();                                           // it has seen every stripe queued, so it runs to the end
+      if (oc.err.load()) return fail(JPEGGPU_ERR_HIP, "download of a stripe: %s", hipGetErrorString((hipError_t)oc.err.load()));
+      HIP_TRY(hipStreamSynchronize(s_down));
+   } else {
+      // drain, oldest stripe first
+      for (uint32_t k = (nstripes >= 2 ? nstripes - 2 : 0); k < nstripes; k++) {
+         HIP_TRY(hipEventSynchronize(ctx->pipe_done[k & 1]));
+         if (!out_pinned) copy_out(k);
+      }
    }
-   drain.armed = false;                                       // both lanes have been waited for
+   HIP_TRY(hipStreamSynchronize(s_up));                       // long since idle: every download waited for its upload
+   drain.armed = false;                                       // both streams have been waited for
    return 0;
 }
 

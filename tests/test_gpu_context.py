@@ -1,5 +1,6 @@
 """GPU suite: per-device contexts (jpeggpu_ctx_*), the threading contract, and the pipelined host-pointer form
-(stripes over two streams; pinned caller memory moved in place, pageable memory staged).  Bit-exact vs the oracle."""
+(stripes over an upload and a download stream; pinned caller memory moved in place, pageable memory staged, large
+pageable outputs emptied by a second host thread).  Bit-exact vs the oracle."""
 import os
 import threading
 
@@ -174,6 +175,50 @@ def test_host_pointer_pipeline(gpu, stripe, pinned):
                     [hp.free() for hp in held]
                 assert np.array_equal(got[:, :rb], want), (samp, w, h, stride)
                 assert np.all(pad == 0xCD)
+    finally:
+        if old is None:
+            os.environ.pop("JPEGGPU_STRIPE_BYTES", None)
+        else:
+            os.environ["JPEGGPU_STRIPE_BYTES"] = old
+        gpu.reload_tuning()
+
+
+@pytest.mark.parametrize("stripe", [1 << 20, 0], ids=["1MiB_stripes", "default"])
+@pytest.mark.parametrize("mix", ["pageable", "pinned_in", "pinned_out"])
+def test_host_pointer_helper_thread(gpu, stripe, mix):
+    """A frame whose raster is above 16 MiB in three stripes and more: with a pageable raster the download staging is emptied
+    by a second host thread (capi.cpp run_host).  Pageable and mixed pinned / pageable caller memory, packed and padded
+    rows, twice in a row on the same context (the staging and the event rings are reused)."""
+    old = os.environ.get("JPEGGPU_STRIPE_BYTES")
+    if stripe:
+        os.environ["JPEGGPU_STRIPE_BYTES"] = str(stripe)
+    gpu.reload_tuning()
+    try:
+        d, planes, want = _frame(4096, 1400, ((2, 2), (1, 1), (1, 1)), 77)
+        assert want.nbytes >= 16 << 20
+        gd = helpers.to_gpu_desc(gpu, d)
+        rb = want.shape[1]
+        for stride in (0, rb + 64):
+            buf = np.full((want.shape[0], stride or rb), 0xCD, dtype=np.uint8)
+            src, held = planes, []
+            if mix == "pinned_in":
+                held = [gpu.PinnedArray(p.shape, p.dtype) for p in planes]
+                for hp, p in zip(held, planes):
+                    hp.array[...] = p
+                src = [hp.array for hp in held]
+            elif mix == "pinned_out":
+                held = [gpu.PinnedArray(buf.shape, buf.dtype)]
+                held[0].array[...] = buf
+                buf = held[0].array
+            try:
+                for _ in range(2):
+                    buf[:, :rb] = 0
+                    got = gpu.backend_run(gd, src, QT, out=buf, out_stride=stride).copy()
+                    assert np.array_equal(got[:, :rb], want), (mix, stride)
+                    assert np.all(buf[:, rb:] == 0xCD)
+            finally:
+                del src, buf
+                [hp.free() for hp in held]
     finally:
         if old is None:
             os.environ.pop("JPEGGPU_STRIPE_BYTES", None)
