@@ -140,9 +140,11 @@ size_t jpeggpu_raster_row_bytes(const jpeggpu_frame_desc_t *desc);
  *           packed rows (the file layout).  Any alignment; at most 2^26 bytes (the kernel reaches a
  *           tile's rows with 32-bit offsets), larger strides return JPEGGPU_ERR_INVALID_ARG.
  *
- * Host-pointer form, synchronous: the frame is cut into stripes of whole MCU rows that alternate between two
- * streams, so that the upload of one stripe, the kernel of the previous and the download of the one before
- * overlap (pinned hipMemcpyAsync both ways; see jpeggpu_host_register below).                            */
+ * Host-pointer form, synchronous: the frame is cut into stripes of whole MCU rows; all uploads run back to back
+ * on one stream, each stripe's kernel and download follow on a second, so that the upload of one stripe, the
+ * kernel of the previous and the download of the one before overlap on the full-duplex link (pinned
+ * hipMemcpyAsync both ways; see jpeggpu_host_alloc / jpeggpu_host_register below).  With a pageable raster of
+ * 16 MiB and more the call starts one helper thread of its own and joins it before it returns.            */
 int jpeggpu_backend_run(const jpeggpu_frame_desc_t *desc,
                         const jpeggpu_blocl16_t *const coef[3],
                         const jpeggpu_qtable_t *const qtables[4],

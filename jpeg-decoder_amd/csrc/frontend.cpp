@@ -5,7 +5,11 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <atomic>
 #include <cstring>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include "../../include/jpeggpu_decode.h"
 
@@ -80,6 +84,17 @@ int HuffTable::build(const uint8_t counts[16], const uint8_t *symbols, unsigned 
       if (nodes[nd].child[0] < 0 && l > 0) { fast[w] = (uint16_t)((l << 8) | nodes[nd].sym); deep[w] = 0; }
       else { fast[w] = 0; deep[w] = nd; }
    }
+   for (unsigned w = 0; w < 1024; w++) {
+      acfast[w] = 0;
+      const unsigned f = fast[w >> 1];
+      if (!f) continue;
+      const unsigned len = f >> 8, sym = f & 0xFF, g = sym & 15;
+      if (g == 0 || g > 10 || len + g > 10) continue;
+      const unsigned v = (w >> (10 - len - g)) & ((1u << g) - 1);
+      const int lo = 1 << (g - 1);
+      const int val = (int)v < lo ? (int)v - ((lo << 1) - 1) : (int)v;   // get_val_from_magnitude, src/vld.c:75-86
+      acfast[w] = (int32_t)(((uint32_t)val << 16) | ((sym >> 4) << 8) | (len + g));
+   }
    present = true;
    return 0;
 }
@@ -88,19 +103,79 @@ int HuffTable::build(const uint8_t counts[16], const uint8_t *symbols, unsigned 
 // Bit-level primitives
 // ---------------------------------------------------------------------------------------------
 
-static inline uint32_t peek_bits(const BitReader &br, unsigned n) {   // 1 <= n <= 32
-   uint64_t v;
-   memcpy(&v, br.buf + (br.pos >> 3), 8);
-   v = __builtin_bswap64(v) << (br.pos & 7);
-   return (uint32_t)(v >> (64 - n));
-}
+// Two ways to read the scan's bits, with one interface, so that every decoder below exists once (as a template):
+//   CheckedBits  the bit position and its end, as the reference's read_bit sees them: any read can run into the
+//                marker (ok() turns false).  Used where the scan is about to end.
+//   FastBits     the next bits in a register, topped up from memory by a branch-free refill; ok() is always true.
+//                Used for a block only when the scan still holds more bits than any block can consume
+//                (kBlockBitsMargin), so that the reference's end-of-data errors cannot occur inside it.
+// window(): the next bits, first bit in bit 63, at least 56 of them valid.
+struct CheckedBits {
+   static constexpr bool kChecked = true;
+   BitReader &br;
+   explicit CheckedBits(BitReader &b) : br(b) {}
+   uint64_t window() const {
+      uint64_t v;
+      memcpy(&v, br.buf + (br.pos >> 3), 8);
+      return __builtin_bswap64(v) << (br.pos & 7);
+   }
+   void skip(unsigned n) { br.pos += n; }
+   bool ok() const { return br.pos < br.limit; }
+   uint64_t pos() const { return br.pos; }
+   uint64_t limit() const { return br.limit; }
+   bool bit(uint32_t &b) {                                    // read_bit, src/bitstream.c:13-23
+      b = (uint32_t)(window() >> 63);
+      br.pos += 1;
+      return br.pos < br.limit;
+   }
+   void done() {}
+};
+
+struct FastBits {
+   static constexpr bool kChecked = false;
+   BitReader &br;
+   const uint8_t *p;
+   uint64_t bits = 0;
+   unsigned n = 0;                                            // valid bits at the top of <bits>; what lies below them are the stream's next bits as well
+   explicit FastBits(BitReader &b) : br(b), p(b.buf + (b.pos >> 3)) {
+      refill();
+      bits <<= (b.pos & 7);
+      n -= (unsigned)(b.pos & 7);
+   }
+   void refill() {
+      uint64_t w;
+      memcpy(&w, p, 8);
+      bits |= __builtin_bswap64(w) >> n;
+      const unsigned adv = (63 - n) >> 3;
+      p += adv;
+      n += adv * 8;                                           // 56..63
+   }
+   uint64_t window() { refill(); return bits; }
+   void skip(unsigned k) { bits <<= k; n -= k; }
+   static constexpr bool ok() { return true; }
+   uint64_t pos() const { return 8 * (uint64_t)(p - br.buf) - n; }
+   uint64_t limit() const { return br.limit; }
+   bool bit(uint32_t &b) {
+      if (n == 0) refill();
+      b = (uint32_t)(bits >> 63);
+      bits <<= 1;
+      n -= 1;
+      return true;
+   }
+   void done() { br.pos = pos(); }                            // hand the position back to the scan's BitReader
+};
+constexpr uint64_t kBlockBitsMargin = 2048;   // > 1 + 63 symbols of 16 + 11 bits (1728); > 63 x (16 + 1) + 63 correction bits + an end-of-band run
+std::atomic<bool> g_force_checked{ false };   // test hook (jpeggpu_internal_vld_force_checked): every block through CheckedBits
+
+static inline bool far_from_end(const BitReader &br) { return br.fast_allowed && br.pos + kBlockBitsMargin < br.limit; }
 
 // get_huffman_symbole (src/vld.c:268-283).  Returns the symbol, or -1 when the walk crossed the end
-// of the scan data (read_bit failing on the byte after 0xFF, src/bitstream.c:13-23).
-// *all_ones: the bits read were all 1 (code_que_un).
-static inline int huff_symbol(BitReader &br, const HuffTable &t, bool *all_ones) {
-   const uint64_t start = br.pos;
-   uint32_t w = peek_bits(br, 16);
+// of the scan data (read_bit failing on the byte after 0xFF, src/bitstream.c:13-23), or -2 for a code no
+// symbol was given to.  *all_ones: the bits read were all 1 (code_que_un).
+template <class R>
+static inline int huff_symbol(R &r, const HuffTable &t, bool *all_ones) {
+   const uint64_t start = r.pos();
+   const uint32_t w = (uint32_t)(r.window() >> 48);
    unsigned f = t.fast[w >> 7], len;
    int sym;
    if (f) {
@@ -114,10 +189,10 @@ static inline int huff_symbol(BitReader &br, const HuffTable &t, bool *all_ones)
       if (t.nodes[nd].child[0] >= 0) return -2;
       sym = t.nodes[nd].sym;
    }
-   br.pos += len;
-   if (br.pos >= br.limit) {
+   r.skip(len);
+   if (!r.ok()) {
       if (all_ones) {   // bits actually read before the failure: start .. limit-1
-         unsigned nb = (unsigned)(br.limit - start);
+         unsigned nb = (unsigned)(r.limit() - start);
          *all_ones = (w >> (16 - nb)) == ((1u << nb) - 1);
       }
       return -1;
@@ -127,12 +202,13 @@ static inline int huff_symbol(BitReader &br, const HuffTable &t, bool *all_ones)
 }
 
 // read_indice (src/vld.c:88-100): n bits, MSB first.  false when the scan data ran out.
-static inline bool read_index(BitReader &br, unsigned n, uint32_t &idx) {
+template <class R>
+static inline bool read_index(R &r, unsigned n, uint32_t &idx) {
    idx = 0;
    if (n == 0) return true;
-   idx = peek_bits(br, n);
-   br.pos += n;
-   return br.pos < br.limit;
+   idx = (uint32_t)(r.window() >> (64 - n));
+   r.skip(n);
+   return r.ok();
 }
 
 // get_val_from_magnitude (src/vld.c:75-86)
@@ -430,6 +506,7 @@ int Decoder::begin_scan(BitReader &br, size_t &scan_begin, size_t &scan_end, siz
    br.buf = scanbuf.data();
    br.pos = 0;
    br.limit = 8 * (uint64_t)nbytes + 8;
+   br.fast_allowed = !g_force_checked.load();
    return 0;
 }
 
@@ -448,7 +525,8 @@ int Decoder::finish_scan(const BitReader &br, size_t scan_begin, size_t scan_end
 }
 
 // decode_coef_DC, first scan of the band (src/vld.c:285-305 + :102-113)
-static inline int dc_first(BitReader &br, const HuffTable &t, unsigned al, int16_t *coef, std::string &err) {
+template <class R>
+static inline int dc_first(R &br, const HuffTable &t, unsigned al, int16_t *coef, std::string &err) {
    bool ones = true;
    int s = huff_symbol(br, t, &ones);
    if (s == -2) { err = "[DHT] table de Huffman DC vide"; return JPEGGPU_ERR_HUFF_BAD; }
@@ -461,19 +539,15 @@ static inline int dc_first(BitReader &br, const HuffTable &t, unsigned al, int16
    return 0;
 }
 
-// decode_coef_AC_first_scan in a loop (src/vld.c:124-174, :307-327).  One 64-bit window per coefficient
+// decode_coef_AC_first_scan in a loop (src/vld.c:124-174, :307-327).  One window per coefficient
 // serves the Huffman code (<= 16 bits) and the value bits (<= 10) that follow it.
-int Decoder::ac_first(BitReader &br, const HuffTable &t, int16_t *blk, uint16_t &skip, const uint16_t *q) {
+template <class R>
+int Decoder::ac_first(R &r, const HuffTable &t, int16_t *blk, uint16_t &skip, const uint16_t *q) {
    unsigned idx = ss;
    skip = 0;
-   const uint8_t *const buf = br.buf;
-   const uint64_t limit = br.limit;
-   uint64_t pos = br.pos;
    const unsigned last = se;
    while (idx <= last) {
-      uint64_t w;
-      memcpy(&w, buf + (pos >> 3), 8);
-      w = __builtin_bswap64(w) << (pos & 7);                 // >= 57 valid bits
+      const uint64_t w = r.window();                         // >= 56 valid bits
       const unsigned f = t.fast[w >> 55];
       unsigned len;
       int s;
@@ -484,46 +558,81 @@ int Decoder::ac_first(BitReader &br, const HuffTable &t, int16_t *blk, uint16_t 
          const uint32_t w16 = (uint32_t)(w >> 48);
          int nd = t.deep[w >> 55];
          len = 9;
-         if (t.nodes[nd].child[0] < 0) { br.pos = pos; return fail(JPEGGPU_ERR_HUFF_BAD, "[DHT] table de Huffman AC vide"); }
+         if (t.nodes[nd].child[0] < 0) return fail(JPEGGPU_ERR_HUFF_BAD, "[DHT] table de Huffman AC vide");
          while (t.nodes[nd].child[0] >= 0 && len < 16) { nd = t.nodes[nd].child[(w16 >> (15 - len)) & 1]; len++; }
-         if (t.nodes[nd].child[0] >= 0) { br.pos = pos; return fail(JPEGGPU_ERR_HUFF_BAD, "[DHT] table de Huffman AC vide"); }
+         if (t.nodes[nd].child[0] >= 0) return fail(JPEGGPU_ERR_HUFF_BAD, "[DHT] table de Huffman AC vide");
          s = t.nodes[nd].sym;
       }
-      pos += len;
-      if (pos >= limit) { br.pos = pos; return fail(JPEGGPU_ERR_0XFF00, "%s", kMsgFF); }
+      r.skip(len);
+      if (!r.ok()) return fail(JPEGGPU_ERR_0XFF00, "%s", kMsgFF);
       if (s == 0xF0) { idx += 16; continue; }
       const unsigned alpha = (unsigned)s >> 4, gamma = (unsigned)s & 15;
       if (gamma == 0) {
-         br.pos = pos;
          if (alpha == 0) { skip = 1; return 0; }
          if (num_sof == 0) return fail(JPEGGPU_ERR_AC_BAD, "Code invalide pour AC (%x) car mode baseline", s);
          if (alpha > 14) return fail(JPEGGPU_ERR_AC_BAD, "EOB%d interdit (max = 14)", alpha);
          uint32_t run;
-         if (!read_index(br, alpha, run)) return fail(JPEGGPU_ERR_0XFF00, "%s", kMsgFF);
+         if (!read_index(r, alpha, run)) return fail(JPEGGPU_ERR_0XFF00, "%s", kMsgFF);
          skip = (uint16_t)(run + (1u << alpha));
          return 0;
       }
       idx += alpha;
-      if (gamma > 10) { br.pos = pos; return fail(JPEGGPU_ERR_AC_BAD, "La magnitude doit être inférieur ou égale à 10"); }
+      if (gamma > 10) return fail(JPEGGPU_ERR_AC_BAD, "La magnitude doit être inférieur ou égale à 10");
       const uint32_t v = (uint32_t)((w << len) >> (64 - gamma));   // len + gamma <= 26 bits of the window
-      pos += gamma;
-      if (pos >= limit) { br.pos = pos; return fail(JPEGGPU_ERR_0XFF00, "%s", kMsgFF); }
-      if (idx > 63) { br.pos = pos; return fail(JPEGGPU_ERR_UNSUPPORTED, "coefficient AC hors du bloc (indice %u)", idx); }   // the reference writes past the block
+      r.skip(gamma);
+      if (!r.ok()) return fail(JPEGGPU_ERR_0XFF00, "%s", kMsgFF);
+      if (idx > 63) return fail(JPEGGPU_ERR_UNSUPPORTED, "coefficient AC hors du bloc (indice %u)", idx);   // the reference writes past the block
       int c = magnitude_value(gamma, v) * (1 << al);
       if (q) c = (int16_t)c * (int)q[idx];                         // iquant, src/iqzz.c:12 (only non-zero coefficients change)
       blk[idx] = (int16_t)c;
       idx++;
    }
-   br.pos = pos;
    return 0;
 }
 
+// Refinement scans walk a block's coefficients one by one and branch on "is it zero" -- a coin toss for the branch
+// predictor.  Away from the end of the scan (FastBits) the walk is replaced by arithmetic on a 64-bit map of the
+// block's non-zero coefficients: the zero that ends a run is found by clearing set bits, and the coefficients that
+// receive a correction bit on the way are the map's set bits in between, visited in ascending order as the walk does.
+static inline uint64_t nonzero_mask(const int16_t *blk) {   // bit i: blk[i] != 0
+#if defined(__SSE2__)
+   const __m128i zero = _mm_setzero_si128();
+   uint64_t m = 0;
+   for (int k = 0; k < 4; k++) {
+      const __m128i a = _mm_cmpeq_epi16(_mm_loadu_si128((const __m128i *)(blk + 16 * k)), zero);
+      const __m128i b = _mm_cmpeq_epi16(_mm_loadu_si128((const __m128i *)(blk + 16 * k + 8)), zero);
+      m |= (uint64_t)(uint16_t)_mm_movemask_epi8(_mm_packs_epi16(a, b)) << (16 * k);   // bit i: blk[i] == 0
+   }
+   return ~m;
+#else
+   uint64_t m = 0;
+   for (int i = 0; i < 64; i++) m |= (uint64_t)(blk[i] != 0) << i;
+   return m;
+#endif
+}
+
+// correction_coef (src/vld.c:177-183) for every position in <m>, ascending: the next bit, OR-ed in at bit <al> whatever the sign
+static inline void correct_positions(FastBits &r, int16_t *blk, uint64_t m, unsigned al) {
+   while (m) {
+      const unsigned i = (unsigned)__builtin_ctzll(m);
+      m &= m - 1;
+      uint32_t b;
+      r.bit(b);
+      blk[i] = (int16_t)(blk[i] | (int16_t)(b << al));
+   }
+}
+
 // correction_eob (src/vld.c:228-238): one correction bit for every non-zero coefficient up to Se
-int Decoder::refine_to_band_end(BitReader &br, int16_t *blk, unsigned idx) {
+template <class R>
+int Decoder::refine_to_band_end(R &br, int16_t *blk, unsigned idx) {
+   if constexpr (!R::kChecked) {                              // no read can fail: visit the non-zero coefficients only
+      if (idx <= se) correct_positions(br, blk, nonzero_mask(blk) & (~0ull << idx) & (~0ull >> (63 - se)), al);
+      return 0;
+   }
    for (; idx <= se; idx++) {
       if (blk[idx] != 0) {
          uint32_t b;
-         if (!read_index(br, 1, b)) return fail(JPEGGPU_ERR_0XFF00, "%s", kMsgFF);
+         if (!br.bit(b)) return fail(JPEGGPU_ERR_0XFF00, "%s", kMsgFF);
          if (b) blk[idx] = (int16_t)(blk[idx] | (int16_t)(1 << al));   // correction_coef, src/vld.c:177-183: OR whatever the sign
       }
    }
@@ -531,9 +640,57 @@ int Decoder::refine_to_band_end(BitReader &br, int16_t *blk, unsigned idx) {
 }
 
 // decode_coef_AC_subsequent_scan in a loop (src/vld.c:185-266, :307-327)
-int Decoder::ac_refine(BitReader &br, const HuffTable &t, int16_t *blk, uint16_t &skip) {
-   unsigned idx = ss;
+template <class R>
+int Decoder::ac_refine(R &br, const HuffTable &t, int16_t *blk, uint16_t &skip) {
    skip = 0;
+   if constexpr (R::kChecked) {
+      return ac_refine_walk(br, t, blk, skip, ss);
+   } else {
+      unsigned idx = ss;
+      const uint64_t nz = nonzero_mask(blk);                  // coefficients this block places itself lie below idx and are never met again
+      while (idx <= se) {
+         const uint8_t *const p0 = br.p;                      // the reader in front of this symbol: anything out of the ordinary
+         const uint64_t bits0 = br.bits;                      // is handed to the coefficient-by-coefficient walk from here
+         const unsigned n0 = br.n;
+         const int s = huff_symbol(br, t, nullptr);
+         if (s < 0) return fail(JPEGGPU_ERR_HUFF_BAD, "[DHT] table de Huffman AC vide");
+         const uint64_t from = ~0ull << idx;                  // idx <= se <= 63
+         const unsigned alpha = (unsigned)s >> 4, gamma = (unsigned)s & 15;
+         if (gamma == 0 && s != 0xF0) {                       // end of band (run)
+            if (alpha == 0) {
+               skip = 1;
+            } else {
+               uint32_t run;
+               read_index(br, alpha, run);
+               skip = (uint16_t)(run + (1u << alpha));
+            }
+            correct_positions(br, blk, nz & from & (~0ull >> (63 - se)), al);
+            return 0;
+         }
+         if (s != 0xF0 && gamma != 1)
+            return fail(JPEGGPU_ERR_AC_BAD, "En progressif les AC qui ne sont pas sur le premier scan doivent être 0xRRRRSSSS avec SSSS=0 ou 1");
+         uint32_t sb = 0;
+         if (s != 0xF0) br.bit(sb);                           // the sign comes before the correction bits
+         // ZRL: the walk stops behind the 16th zero.  (run, 1): behind <run> zeros it goes on to the next zero, which
+         // takes the new coefficient -- the (run + 1)-th zero from here.
+         uint64_t z = ~nz & from;
+         for (unsigned k = (s == 0xF0 ? 15 : alpha); k != 0 && z; k--) z &= z - 1;
+         if (!z) {                                            // the block has not that many zeros left: the reference runs out of it
+            br.p = p0; br.bits = bits0; br.n = n0;
+            return ac_refine_walk(br, t, blk, skip, idx);
+         }
+         const unsigned T = (unsigned)__builtin_ctzll(z);
+         correct_positions(br, blk, nz & from & ((1ull << T) - 1), al);
+         if (s != 0xF0) blk[T] = (int16_t)((sb ? 1 : -1) * (1 << al));
+         idx = T + 1;
+      }
+      return 0;
+   }
+}
+
+// ... and the same, coefficient by coefficient as the reference does it (src/vld.c:185-266), from coefficient <idx> on
+template <class R>
+int Decoder::ac_refine_walk(R &br, const HuffTable &t, int16_t *blk, uint16_t &skip, unsigned idx) {
    const int16_t bitv = (int16_t)(1 << al);
    // correction_n_coef (src/vld.c:185-198): pass <n> zero coefficients, correcting the non-zero ones met
    auto pass_zeros = [&](unsigned n) -> int {
@@ -542,7 +699,7 @@ int Decoder::ac_refine(BitReader &br, const HuffTable &t, int16_t *blk, uint16_t
          if (idx > 63) return fail(JPEGGPU_ERR_UNSUPPORTED, "plage de zéros hors du bloc");   // the reference reads past the block
          if (blk[idx] != 0) {
             uint32_t b;
-            if (!read_index(br, 1, b)) return fail(JPEGGPU_ERR_0XFF00, "%s", kMsgFF);
+            if (!br.bit(b)) return fail(JPEGGPU_ERR_0XFF00, "%s", kMsgFF);
             if (b) blk[idx] = (int16_t)(blk[idx] | bitv);
          } else {
             z++;
@@ -575,14 +732,14 @@ int Decoder::ac_refine(BitReader &br, const HuffTable &t, int16_t *blk, uint16_t
       // skip_n_coef_AC_subsequent_scan (src/vld.c:212-222): sign bit first, then the zero run, then the
       // non-zero coefficients up to the next zero, which receives +-(1<<al)
       uint32_t sb;
-      if (!read_index(br, 1, sb)) return fail(JPEGGPU_ERR_0XFF00, "%s", kMsgFF);
+      if (!br.bit(sb)) return fail(JPEGGPU_ERR_0XFF00, "%s", kMsgFF);
       int rc = pass_zeros(alpha);
       if (rc) return rc;
       while (true) {
          if (idx > 63) return fail(JPEGGPU_ERR_UNSUPPORTED, "nouveau coefficient hors du bloc");
          if (blk[idx] == 0) break;
          uint32_t b;
-         if (!read_index(br, 1, b)) return fail(JPEGGPU_ERR_0XFF00, "%s", kMsgFF);
+         if (!br.bit(b)) return fail(JPEGGPU_ERR_0XFF00, "%s", kMsgFF);
          if (b) blk[idx] = (int16_t)(blk[idx] | bitv);
          idx++;
       }
@@ -590,6 +747,115 @@ int Decoder::ac_refine(BitReader &br, const HuffTable &t, int16_t *blk, uint16_t
       idx++;
    }
    return 0;
+}
+
+// One whole block of a baseline scan (decode_bloc_acdc_baseline, src/vld.c:329-343, with Al = 0) for the case that
+// nothing is wrong with it.  The caller has made sure that the scan holds more bits than any block can take (1 DC +
+// 63 AC symbols of at most 16 + 11 bits), so no read can run into the marker; the bits sit in a register that is
+// topped up from memory once per symbol, which keeps the address arithmetic of the checked path (bit position ->
+// byte load -> swap -> shift) off the dependency chain from one symbol to the next.  Anything the reference treats
+// as an error, or that this path does not handle (an unused code, a magnitude out of range, a run past the block, an
+// end-of-band run), returns false: the caller decodes the block again from the same bit position by the checked
+// path, which stores the same coefficients up to that point and then reports what the reference reports.
+template <bool Q>   // Q: store coefficient * q[index] (iquant at store time, src/iqzz.c:12)
+__attribute__((always_inline)) static inline bool baseline_block_fast(const uint8_t *buf, uint64_t &pos_io, const HuffTable &tdc, const HuffTable &tac,
+                                       int16_t *blk, int16_t pred, int16_t &dc_out, const uint16_t *q) {
+   const uint8_t *p = buf + (pos_io >> 3);
+   uint64_t bits = 0;
+   unsigned n = 0;                        // valid bits at the top of <bits>; the bits below them are the stream's next ones too
+#define JFE_REFILL()                                                           \
+   do {                                                                        \
+      uint64_t w_;                                                             \
+      memcpy(&w_, p, 8);                                                       \
+      bits |= __builtin_bswap64(w_) >> n;                                      \
+      const unsigned adv_ = (63 - n) >> 3;                                     \
+      p += adv_;                                                               \
+      n += adv_ * 8;                       /* 56..63 */                        \
+   } while (0)
+   JFE_REFILL();
+   bits <<= (pos_io & 7);
+   n -= (unsigned)(pos_io & 7);
+   JFE_REFILL();
+   // DC: decode_coef_DC (src/vld.c:285-305)
+   {
+      unsigned f = tdc.fast[bits >> 55], len, s;
+      if (f) {
+         len = f >> 8;
+         s = f & 0xFF;
+      } else {
+         const uint32_t w16 = (uint32_t)(bits >> 48);
+         int nd = tdc.deep[bits >> 55];
+         len = 9;
+         if (tdc.nodes[nd].child[0] < 0) return false;
+         while (tdc.nodes[nd].child[0] >= 0 && len < 16) { nd = tdc.nodes[nd].child[(w16 >> (15 - len)) & 1]; len++; }
+         if (tdc.nodes[nd].child[0] >= 0) return false;
+         s = tdc.nodes[nd].sym;
+      }
+      if ((bits >> (64 - len)) == ((1ull << len) - 1)) return false;   // the all-ones code
+      if (s > 11) return false;
+      bits <<= len;
+      n -= len;
+      int v = 0;
+      if (s) {
+         const uint32_t idx = (uint32_t)(bits >> (64 - s));
+         bits <<= s;
+         n -= s;
+         v = magnitude_value(s, idx);
+      }
+      const int16_t dc = (int16_t)((int16_t)v + pred);
+      dc_out = dc;
+      blk[0] = Q ? (int16_t)(dc * (int)q[0]) : dc;
+   }
+   // AC: decode_coef_AC_first_scan, Ss = 1, Se = 63 (src/vld.c:124-174)
+   unsigned idx = 1;
+   while (idx <= 63) {
+      JFE_REFILL();
+      const int32_t e = tac.acfast[bits >> 54];
+      if (e) {                                                  // code + value within 10 bits
+         const unsigned tl = (unsigned)e & 0xFF;
+         idx += ((unsigned)e >> 8) & 15;
+         if (idx > 63) return false;
+         bits <<= tl;
+         n -= tl;
+         const int c = e >> 16;
+         blk[idx] = Q ? (int16_t)((int16_t)c * (int)q[idx]) : (int16_t)c;
+         idx++;
+         continue;
+      }
+      unsigned f = tac.fast[bits >> 55], len, s;
+      if (f) {
+         len = f >> 8;
+         s = f & 0xFF;
+      } else {
+         const uint32_t w16 = (uint32_t)(bits >> 48);
+         int nd = tac.deep[bits >> 55];
+         len = 9;
+         if (tac.nodes[nd].child[0] < 0) return false;
+         while (tac.nodes[nd].child[0] >= 0 && len < 16) { nd = tac.nodes[nd].child[(w16 >> (15 - len)) & 1]; len++; }
+         if (tac.nodes[nd].child[0] >= 0) return false;
+         s = tac.nodes[nd].sym;
+      }
+      bits <<= len;
+      n -= len;
+      if (s == 0xF0) { idx += 16; continue; }
+      const unsigned alpha = s >> 4, gamma = s & 15;
+      if (gamma == 0) {
+         if (alpha == 0) break;                                 // end of block
+         return false;
+      }
+      if (gamma > 10) return false;
+      idx += alpha;
+      if (idx > 63) return false;
+      const uint32_t v = (uint32_t)(bits >> (64 - gamma));
+      bits <<= gamma;
+      n -= gamma;
+      const int c = magnitude_value(gamma, v);
+      blk[idx] = Q ? (int16_t)((int16_t)c * (int)q[idx]) : (int16_t)c;
+      idx++;
+   }
+#undef JFE_REFILL
+   pos_io = 8 * (uint64_t)(p - buf) - n;
+   return true;
 }
 
 // The MCU walk of decode_baseline_image (src/baseline.c:160-199) with decode_bloc_acdc_baseline
@@ -604,6 +870,9 @@ int Decoder::scan_baseline(BitReader &br) {
    }
    if (nsc != nbcomp) return fail(JPEGGPU_ERR_UNSUPPORTED, "scan baseline sans toutes les composantes");
    const uint8_t ss0 = ss;
+   // the unchecked block decoder serves the regular case: Al = 0, the band 1..63 (the reference decodes Ss = 1 .. Se
+   // whatever the header says only as far as Se, src/vld.c:329-343) and enough bits left for any block
+   const bool fast_ok = al == 0 && se == 63;
    mcu_rows_done = 0;
    for (uint32_t my = 0; my < nbmcuV; my++) {
       for (uint32_t mx = 0; mx < nbmcuH; mx++) {
@@ -618,15 +887,22 @@ int Decoder::scan_baseline(BitReader &br) {
                   if (ci.idhac > 3 || !hac[ci.idhac].present) return fail(JPEGGPU_ERR_NO_HT, "Pas de table de huffman AC pour la composante %d", c);
                   if (ci.idq > 3 || !qt_present[ci.idq]) return fail(JPEGGPU_ERR_NO_HT, "Pas de table de quantification pour la composante %d", c);
                   int16_t *blk = plane[c] + (((size_t)my * ci.vs + by) * nbH + (size_t)mx * ci.hs + bx) * 64;
-                  int rc = dc_first(br, hdc[ci.idhdc], al, blk, err);
+                  const uint16_t *q = dequant_on_store ? qt[ci.idq] : nullptr;
+                  if (fast_ok && far_from_end(br)) {
+                     int16_t dc;
+                     const bool done = q ? baseline_block_fast<true>(br.buf, br.pos, hdc[ci.idhdc], hac[ci.idhac], blk, pred[c], dc, q)
+                                         : baseline_block_fast<false>(br.buf, br.pos, hdc[ci.idhdc], hac[ci.idhac], blk, pred[c], dc, q);
+                     if (done) { pred[c] = dc; continue; }
+                  }
+                  CheckedBits cb(br);
+                  int rc = dc_first(cb, hdc[ci.idhdc], al, blk, err);
                   if (rc) return rc;
                   blk[0] = (int16_t)(blk[0] + pred[c]);
                   pred[c] = blk[0];
-                  const uint16_t *q = dequant_on_store ? qt[ci.idq] : nullptr;
                   if (q) blk[0] = (int16_t)(blk[0] * (int)q[0]);
                   uint16_t skip;
                   ss = 1;
-                  rc = ac_first(br, hac[ci.idhac], blk, skip, q);
+                  rc = ac_first(cb, hac[ci.idhac], blk, skip, q);
                   ss = ss0;
                   if (rc) return rc;
                }
@@ -662,11 +938,20 @@ int Decoder::scan_progressive_dc(BitReader &br) {
                   int16_t *blk = plane[c] + (((size_t)my * ci.vs + by) * nbH + (size_t)mx * ci.hs + bx) * 64;
                   if (ah != 0) {
                      if (ah - al != 1) return fail(JPEGGPU_ERR_DIFF_AH_AL, "La différence entre ah et al devrait être 1");
+                     CheckedBits cb(br);
                      uint32_t b;
-                     if (!read_index(br, 1, b)) return fail(JPEGGPU_ERR_0XFF00, "%s", kMsgFF);
+                     if (!cb.bit(b)) return fail(JPEGGPU_ERR_0XFF00, "%s", kMsgFF);
                      blk[0] = (int16_t)(blk[0] | (int16_t)(b << al));   // src/vld.c:115-122
                   } else {
-                     int rc = dc_first(br, hdc[ci.idhdc], al, blk, err);
+                     int rc;
+                     if (far_from_end(br)) {
+                        FastBits fb(br);
+                        rc = dc_first(fb, hdc[ci.idhdc], al, blk, err);
+                        fb.done();
+                     } else {
+                        CheckedBits cb(br);
+                        rc = dc_first(cb, hdc[ci.idhdc], al, blk, err);
+                     }
                      if (rc) return rc;
                      blk[0] = (int16_t)(blk[0] + pred[c]);
                   }
@@ -700,18 +985,29 @@ int Decoder::scan_progressive_ac(BitReader &br) {
          if (skip == 0) {
             if (ci.idhac > 3 || !hac[ci.idhac].present)   // src/progressive.c:58-62 (Se != 0 here)
                return fail(JPEGGPU_ERR_NO_HT, "Pas de table de huffman AC pour la composante %d", c);
+            if (ah != 0 && ah - al != 1) return fail(JPEGGPU_ERR_DIFF_AH_AL, "La différence entre ah et al devrait être 1");
             int rc;
-            if (ah == 0) {
-               rc = ac_first(br, hac[ci.idhac], blk, skip);
+            if (far_from_end(br)) {       // far from the end of the scan: no read of this block can fail
+               FastBits fb(br);
+               rc = ah == 0 ? ac_first(fb, hac[ci.idhac], blk, skip, nullptr) : ac_refine(fb, hac[ci.idhac], blk, skip);
+               fb.done();
             } else {
-               if (ah - al != 1) return fail(JPEGGPU_ERR_DIFF_AH_AL, "La différence entre ah et al devrait être 1");
-               rc = ac_refine(br, hac[ci.idhac], blk, skip);
+               CheckedBits cb(br);
+               rc = ah == 0 ? ac_first(cb, hac[ci.idhac], blk, skip, nullptr) : ac_refine(cb, hac[ci.idhac], blk, skip);
             }
             if (rc) return rc;
             if (skip != 0) skip--;   // src/progressive.c:68
          } else {
             if (ah != 0) {
-               int rc = refine_to_band_end(br, blk, ss);
+               int rc;
+               if (far_from_end(br)) {
+                  FastBits fb(br);
+                  rc = refine_to_band_end(fb, blk, ss);
+                  fb.done();
+               } else {
+                  CheckedBits cb(br);
+                  rc = refine_to_band_end(cb, blk, ss);
+               }
                if (rc) return rc;
             }
             skip--;
@@ -754,3 +1050,8 @@ int Decoder::decode_scan() {
 }
 
 }  // namespace jpegfe
+
+// Test hook: decode every block with the reader that checks for the end of the scan on every read (the form that mirrors
+// the reference's read_bit line by line); tests compare it with the default, in which only the last 256 bytes of a scan
+// are decoded that way.
+extern "C" void jpeggpu_internal_vld_force_checked(int on) { jpegfe::g_force_checked.store(on != 0); }

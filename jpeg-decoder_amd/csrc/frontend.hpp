@@ -24,6 +24,9 @@ struct HuffTable {
    std::vector<Node> nodes;
    uint16_t fast[512];   // (length << 8) | symbol for codes of <= 9 bits, else 0
    int32_t deep[512];    // node reached after 9 bits when fast[] is 0
+   // AC coefficient in one look-up: index = the next 10 bits; (value << 16) | (zero run << 8) | (code length + value bits)
+   // when code and value bits fit into those 10 bits and the symbol carries a value (SSSS 1..10), else 0
+   int32_t acfast[1024];
    bool present = false;
    int build(const uint8_t counts[16], const uint8_t *symbols, unsigned nsym);   // 0 or ERR_HUFF_BAD
 };
@@ -34,6 +37,7 @@ struct BitReader {
    const uint8_t *buf = nullptr;   // un-stuffed scan bytes + the marker's 0xFF + zero guard
    uint64_t pos = 0;               // bits consumed
    uint64_t limit = 0;             // consuming bit <limit-1> (the 8th bit of the marker's 0xFF) is an error
+   bool fast_allowed = true;       // blocks far from the end of the scan may use the unchecked reader (frontend.cpp FastBits)
 };
 
 struct Decoder {
@@ -102,9 +106,11 @@ struct Decoder {
    int scan_baseline(BitReader &br);
    int scan_progressive_dc(BitReader &br);
    int scan_progressive_ac(BitReader &br);
-   int ac_first(BitReader &br, const HuffTable &t, int16_t *blk, uint16_t &skip, const uint16_t *q = nullptr);
-   int ac_refine(BitReader &br, const HuffTable &t, int16_t *blk, uint16_t &skip);
-   int refine_to_band_end(BitReader &br, int16_t *blk, unsigned idx);
+   // R: CheckedBits / FastBits (frontend.cpp)
+   template <class R> int ac_first(R &r, const HuffTable &t, int16_t *blk, uint16_t &skip, const uint16_t *q);
+   template <class R> int ac_refine(R &r, const HuffTable &t, int16_t *blk, uint16_t &skip);
+   template <class R> int ac_refine_walk(R &r, const HuffTable &t, int16_t *blk, uint16_t &skip, unsigned idx);
+   template <class R> int refine_to_band_end(R &r, int16_t *blk, unsigned idx);
 };
 
 }  // namespace jpegfe

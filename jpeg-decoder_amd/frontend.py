@@ -49,6 +49,13 @@ lib.jpeggpu_write_pnm.argtypes = [C.c_char_p, C.POINTER(B.FrameDesc), _vp, _sz]
 lib.jpeggpu_write_pnm_rows.argtypes = [C.c_char_p, C.POINTER(B.FrameDesc), _vp, _sz, _sz]
 lib.jpeggpu_out_file_name.argtypes = [C.c_char_p, C.c_char_p, C.c_uint8, C.c_uint8, C.c_char_p, _sz]
 lib.jpeggpu_jpeg2ppm.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]
+lib.jpeggpu_internal_vld_force_checked.argtypes = [C.c_int]
+lib.jpeggpu_internal_vld_force_checked.restype = None
+
+
+def vld_force_checked(on):
+    """Test hook: entropy-decode every block with the reader that checks for the end of the scan at every read."""
+    lib.jpeggpu_internal_vld_force_checked(1 if on else 0)
 
 
 class Jpeg:
