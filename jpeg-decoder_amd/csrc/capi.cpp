@@ -522,8 +522,11 @@ int jpeggpu_init(int device) {
    return 0;
 }
 
+void jpeggpu_internal_pool_drain(void);   // decode_api.cpp: buffers of closed files kept for the next one
+
 void jpeggpu_shutdown(void) {
    std::lock_guard<std::mutex> lk(g_mu);
+   jpeggpu_internal_pool_drain();
    jpeggpu_ctx_s *c = g_default.exchange(nullptr);
    ctx_delete(c);
 }

@@ -16,7 +16,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/jpeggpu_decode.h"
 #include "kernels.h"
@@ -43,6 +45,7 @@ extern "C" int jpeggpu_internal_ensure_init(void);
 struct jpeggpu_jpeg {
    jpegfe::Decoder d;
    bool pinned = false;
+   int device = -1;               // the device the buffers belong to (the library's default context at open time)
    size_t plane_bytes[3] = { 0, 0, 0 };
    // device side, created by the first render
    bool gpu = false;
@@ -75,6 +78,76 @@ int report(jpeggpu_jpeg *j, int rc) {
       }                                                                                      \
    } while (0)
 
+// ---- buffers kept between files -------------------------------------------------------------------------------------
+// A fresh pinned buffer costs little to allocate but 0.1-0.3 ms per MB when the CPU first touches it (page faults:
+// 30 ms for the planes of a 4096x4096 4:4:4 file, profiles/r02_probe_alloc.txt), against 1 ms to clear one that has been
+// touched before.  A closed file's buffers (pinned planes and raster, device planes and raster) are therefore kept, up
+// to JPEGGPU_POOL_BYTES per kind (default 1 GiB, 0 = keep nothing), and handed to the next file that needs one of
+// exactly that size on the same device -- the serving pattern of many files of one geometry.  jpeggpu_shutdown frees them.
+struct Cached { void *p; size_t bytes; int device; bool host; };
+std::mutex g_pool_mu;
+std::vector<Cached> g_pool;                 // oldest first
+size_t g_pool_held[2] = { 0, 0 };           // [host]
+
+size_t pool_limit() {
+   static const size_t v = [] { const char *e = getenv("JPEGGPU_POOL_BYTES"); return e ? (size_t)atoll(e) : ((size_t)1 << 30); }();
+   return v;
+}
+
+void pool_release(const Cached &c) {
+   if (c.host) (void)hipHostFree(c.p);
+   else (void)hipFree(c.p);
+}
+
+void *pool_take(bool host, size_t bytes, int device) {
+   std::lock_guard<std::mutex> lk(g_pool_mu);
+   for (size_t i = g_pool.size(); i-- > 0;)
+      if (g_pool[i].host == host && g_pool[i].device == device && g_pool[i].bytes == bytes) {
+         void *p = g_pool[i].p;
+         g_pool_held[host] -= bytes;
+         g_pool.erase(g_pool.begin() + (long)i);
+         return p;
+      }
+   return nullptr;
+}
+
+void pool_give(bool host, void *p, size_t bytes, int device) {
+   if (!p) return;
+   std::vector<Cached> out;
+   {
+      std::lock_guard<std::mutex> lk(g_pool_mu);
+      if (bytes > pool_limit() || device < 0) {
+         out.push_back(Cached{ p, bytes, device, host });
+      } else {
+         g_pool.push_back(Cached{ p, bytes, device, host });
+         g_pool_held[host] += bytes;
+         for (size_t i = 0; g_pool_held[host] > pool_limit() && i < g_pool.size();) {
+            if (g_pool[i].host != host) { i++; continue; }
+            out.push_back(g_pool[i]);
+            g_pool_held[host] -= g_pool[i].bytes;
+            g_pool.erase(g_pool.begin() + (long)i);
+         }
+      }
+   }
+   for (const Cached &c : out) pool_release(c);
+}
+
+int current_device() {
+   int dev = -1;
+   if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return -1; }
+   return dev;
+}
+
+hipError_t host_alloc(void **p, size_t bytes, int device) {
+   if ((*p = pool_take(true, bytes, device))) return hipSuccess;
+   return hipHostMalloc(p, bytes, hipHostMallocDefault);
+}
+
+hipError_t dev_alloc(void **p, size_t bytes, int device) {
+   if ((*p = pool_take(false, bytes, device))) return hipSuccess;
+   return hipMalloc(p, bytes);
+}
+
 bool have_device() {
    int n = 0;
    return hipGetDeviceCount(&n) == hipSuccess && n > 0;
@@ -83,13 +156,14 @@ bool have_device() {
 int alloc_planes(jpeggpu_jpeg *j) {
    jpegfe::Decoder &d = j->d;
    j->pinned = have_device() && jpeggpu_internal_ensure_init() == 0;
+   j->device = j->pinned ? current_device() : -1;
    for (int c = 0; c < d.nbcomp; c++) {
       size_t bytes = d.plane_blocks(c) * sizeof(jpeggpu_blocl16_t);
       j->plane_bytes[c] = bytes;
       void *p = nullptr;
       if (bytes == 0) bytes = 128;
       if (j->pinned) {
-         if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) p = nullptr;
+         if (host_alloc(&p, bytes, j->device) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
       } else {
          p = malloc(bytes);
       }
@@ -99,7 +173,7 @@ int alloc_planes(jpeggpu_jpeg *j) {
       // progressive files: DC scans also leave their coefficients packed (2 bytes per block) for the per-scan hand-off
       if (j->pinned && d.num_sof == 2 && j->plane_bytes[c] >= 128) {
          void *q = nullptr;
-         if (hipHostMalloc(&q, j->plane_bytes[c] / 64, hipHostMallocDefault) == hipSuccess) { memset(q, 0, j->plane_bytes[c] / 64); d.dc_pack[c] = (int16_t *)q; }
+         if (host_alloc(&q, j->plane_bytes[c] / 64, j->device) == hipSuccess) { memset(q, 0, j->plane_bytes[c] / 64); d.dc_pack[c] = (int16_t *)q; }
          else (void)hipGetLastError();   // no packed side: whole planes are uploaded
       }
    }
@@ -109,15 +183,17 @@ int alloc_planes(jpeggpu_jpeg *j) {
 void free_all(jpeggpu_jpeg *j) {
    // every member is released on its own: a render that failed half-way through its allocations leaves some set
    if (j->stream) (void)hipStreamSynchronize(j->stream);
-   for (int c = 0; c < 3; c++) if (j->d_plane[c]) (void)hipFree(j->d_plane[c]);
-   for (int c = 0; c < 3; c++) if (j->d_pack[c]) (void)hipFree(j->d_pack[c]);
-   for (int c = 0; c < 3; c++) if (j->d.dc_pack[c]) (void)hipHostFree(j->d.dc_pack[c]);
-   if (j->d_out) (void)hipFree(j->d_out);
-   if (j->h_out) (void)hipHostFree(j->h_out);
+   // buffers go to the cache (pool_give frees what it will not keep); sizes as they were asked for
+   const int dev = j->device;
+   for (int c = 0; c < 3; c++) pool_give(false, j->d_plane[c], j->plane_bytes[c] ? j->plane_bytes[c] : 128, dev);
+   for (int c = 0; c < 3; c++) pool_give(false, j->d_pack[c], j->plane_bytes[c] / 64, dev);
+   for (int c = 0; c < 3; c++) pool_give(true, j->d.dc_pack[c], j->plane_bytes[c] / 64, dev);
+   pool_give(false, j->d_out, j->out_bytes ? j->out_bytes : 16, dev);
+   pool_give(true, j->h_out, j->out_bytes ? j->out_bytes : 16, dev);
    if (j->uploaded) (void)hipEventDestroy(j->uploaded);
    if (j->stream) (void)hipStreamDestroy(j->stream);
    for (int c = 0; c < 3; c++)
-      if (j->d.plane[c]) { if (j->pinned) (void)hipHostFree(j->d.plane[c]); else free(j->d.plane[c]); }
+      if (j->d.plane[c]) { if (j->pinned) pool_give(true, j->d.plane[c], j->plane_bytes[c] ? j->plane_bytes[c] : 128, dev); else free(j->d.plane[c]); }
    delete j;
 }
 
@@ -160,14 +236,15 @@ int render_begin(jpeggpu_jpeg *j) {
       if (!j->stream) HIP_TRYD(hipStreamCreateWithFlags(&j->stream, hipStreamNonBlocking));
       if (!j->uploaded) HIP_TRYD(hipEventCreateWithFlags(&j->uploaded, hipEventDisableTiming));
       for (int c = 0; c < d.nbcomp; c++) {
-         if (!j->d_plane[c]) HIP_TRYD(hipMalloc(&j->d_plane[c], j->plane_bytes[c] ? j->plane_bytes[c] : 128));
-         if (d.dc_pack[c] && !j->d_pack[c]) HIP_TRYD(hipMalloc(&j->d_pack[c], j->plane_bytes[c] / 64));
+         if (!j->d_plane[c]) HIP_TRYD(dev_alloc(&j->d_plane[c], j->plane_bytes[c] ? j->plane_bytes[c] : 128, j->device));
+         if (d.dc_pack[c] && !j->d_pack[c]) HIP_TRYD(dev_alloc(&j->d_pack[c], j->plane_bytes[c] / 64, j->device));
          d.dirty[c] = true;
          if (d.dirty_kind[c] == jpegfe::Decoder::kClean) d.dirty_kind[c] = jpegfe::Decoder::kWhole;   // nothing decoded yet: the (zero) plane as it is
       }
       j->out_bytes = jpeggpu_raster_rows(&desc) * jpeggpu_raster_row_bytes(&desc);
-      if (!j->d_out) HIP_TRYD(hipMalloc(&j->d_out, j->out_bytes ? j->out_bytes : 16));
-      if (!j->h_out) HIP_TRYD(hipHostMalloc((void **)&j->h_out, j->out_bytes ? j->out_bytes : 16, hipHostMallocDefault));
+      if (j->device < 0) j->device = current_device();
+      if (!j->d_out) HIP_TRYD(dev_alloc(&j->d_out, j->out_bytes ? j->out_bytes : 16, j->device));
+      if (!j->h_out) HIP_TRYD(host_alloc((void **)&j->h_out, j->out_bytes ? j->out_bytes : 16, j->device));
       j->gpu = true;
    }
    // Per-scan hand-off (src/progressive.c:209-331 runs the whole back end after every scan): a component that only DC
@@ -240,6 +317,17 @@ std::string out_name(const char *filepath, const char *outfile, uint8_t nbcomp, 
 }  // namespace
 
 extern "C" {
+
+// jpeggpu_shutdown (capi.cpp): nothing of the cache outlives the library's default context
+void jpeggpu_internal_pool_drain(void) {
+   std::vector<Cached> all;
+   {
+      std::lock_guard<std::mutex> lk(g_pool_mu);
+      all.swap(g_pool);
+      g_pool_held[0] = g_pool_held[1] = 0;
+   }
+   for (const Cached &c : all) pool_release(c);
+}
 
 int jpeggpu_jpeg_open_memory(const uint8_t *data, size_t len, jpeggpu_jpeg_t **out) {
    if (!data || !out) { jpeggpu_internal_set_error("NULL argument"); return JPEGGPU_ERR_INVALID_ARG; }

@@ -10,6 +10,10 @@
 #if defined(__SSE2__)
 #include <emmintrin.h>
 #endif
+#if defined(__x86_64__) && (defined(__GNUC__) || defined(__clang__))
+#include <immintrin.h>
+#define JFE_HAVE_BMI2_PATH 1
+#endif
 
 #include "../../include/jpeggpu_decode.h"
 
@@ -165,7 +169,10 @@ struct FastBits {
    void done() { br.pos = pos(); }                            // hand the position back to the scan's BitReader
 };
 constexpr uint64_t kBlockBitsMargin = 2048;   // > 1 + 63 symbols of 16 + 11 bits (1728); > 63 x (16 + 1) + 63 correction bits + an end-of-band run
-std::atomic<bool> g_force_checked{ false };   // test hook (jpeggpu_internal_vld_force_checked): every block through CheckedBits
+std::atomic<int> g_vld_mode{ 0 };   // test hook (jpeggpu_internal_vld_force_checked): 1 = every block through CheckedBits, 2 = no BMI2 code
+#if defined(JFE_HAVE_BMI2_PATH)
+static bool cpu_has_bmi2() { static const bool v = __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("popcnt"); return v; }
+#endif
 
 static inline bool far_from_end(const BitReader &br) { return br.fast_allowed && br.pos + kBlockBitsMargin < br.limit; }
 
@@ -506,7 +513,10 @@ int Decoder::begin_scan(BitReader &br, size_t &scan_begin, size_t &scan_end, siz
    br.buf = scanbuf.data();
    br.pos = 0;
    br.limit = 8 * (uint64_t)nbytes + 8;
-   br.fast_allowed = !g_force_checked.load();
+   br.fast_allowed = g_vld_mode.load() != 1;
+#if defined(JFE_HAVE_BMI2_PATH)
+   br.bmi2 = cpu_has_bmi2() && g_vld_mode.load() == 0;
+#endif
    return 0;
 }
 
@@ -622,11 +632,112 @@ static inline void correct_positions(FastBits &r, int16_t *blk, uint64_t m, unsi
    }
 }
 
+// The correction bits of one block, gathered as a bit map (bit i: coefficient i receives 1 << al) and OR-ed in at the end
+static inline void apply_corrections(int16_t *blk, uint64_t corr, unsigned al) {
+#if defined(__SSE2__)
+   const __m128i sel = _mm_setr_epi16(1, 2, 4, 8, 16, 32, 64, 128);
+   const __m128i bitv = _mm_set1_epi16((short)(1 << al));
+   for (int g = 0; g < 8; g++) {
+      const unsigned byte = (unsigned)(corr >> (8 * g)) & 0xFF;
+      if (!byte) continue;
+      __m128i v = _mm_and_si128(_mm_set1_epi16((short)byte), sel);
+      v = _mm_and_si128(_mm_cmpeq_epi16(v, sel), bitv);
+      __m128i *p = (__m128i *)(blk + 8 * g);
+      _mm_storeu_si128(p, _mm_or_si128(_mm_loadu_si128(p), v));
+   }
+#else
+   for (; corr; corr &= corr - 1) { const unsigned i = (unsigned)__builtin_ctzll(corr); blk[i] = (int16_t)(blk[i] | (int16_t)(1 << al)); }
+#endif
+}
+
+#if defined(JFE_HAVE_BMI2_PATH)
+static inline uint64_t bitrev64(uint64_t x) {
+   x = __builtin_bswap64(x);
+   x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+   x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+   x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+   return x;
+}
+
+// One stream bit for every set bit of <m>, the first bit for the lowest position (the order of the reference's walk);
+// returned at those positions.  PDEP hands the low bits of its source to the set bits of the mask in ascending order,
+// so the window is mirrored first (its first bit is bit 63).
+__attribute__((target("bmi2,popcnt")))
+static inline uint64_t take_corrections(FastBits &r, uint64_t m) {
+   const unsigned c = (unsigned)__builtin_popcountll(m);
+   if (__builtin_expect(c > 56, 0)) {                         // more bits than one window holds: the two halves of the block separately
+      const uint64_t lo = take_corrections(r, m & 0xFFFFFFFFull);
+      return lo | take_corrections(r, m & ~0xFFFFFFFFull);
+   }
+   const uint64_t got = _pdep_u64(bitrev64(r.window()), m);
+   r.skip(c);
+   return got;
+}
+
+// decode_coef_AC_subsequent_scan for one block without a branch per coefficient: the zero that ends a run is selected
+// with PDEP, the correction bits on the way are deposited into a bit map and OR-ed into the block once
+__attribute__((target("bmi2,popcnt")))
+int Decoder::ac_refine_bmi2(FastBits &br, const HuffTable &t, int16_t *blk, uint16_t &skip) {
+   unsigned idx = ss;
+   const uint64_t nz = nonzero_mask(blk);
+   uint64_t corr = 0;
+   int rc = 0;
+   while (idx <= se) {
+      const uint8_t *const p0 = br.p;
+      const uint64_t bits0 = br.bits;
+      const unsigned n0 = br.n;
+      const int s = huff_symbol(br, t, nullptr);
+      if (s < 0) { rc = fail(JPEGGPU_ERR_HUFF_BAD, "[DHT] table de Huffman AC vide"); break; }
+      const uint64_t from = ~0ull << idx;
+      const unsigned alpha = (unsigned)s >> 4, gamma = (unsigned)s & 15;
+      if (gamma == 0 && s != 0xF0) {
+         if (alpha == 0) {
+            skip = 1;
+         } else {
+            uint32_t run;
+            read_index(br, alpha, run);
+            skip = (uint16_t)(run + (1u << alpha));
+         }
+         corr |= take_corrections(br, nz & from & (~0ull >> (63 - se)));
+         break;
+      }
+      if (s != 0xF0 && gamma != 1) {
+         rc = fail(JPEGGPU_ERR_AC_BAD, "En progressif les AC qui ne sont pas sur le premier scan doivent être 0xRRRRSSSS avec SSSS=0 ou 1");
+         break;
+      }
+      uint32_t sb = 0;
+      if (s != 0xF0) br.bit(sb);
+      const uint64_t sel = _pdep_u64(1ull << (s == 0xF0 ? 15 : alpha), ~nz & from);   // the 16th / (run + 1)-th zero from here
+      if (!sel) {
+         br.p = p0; br.bits = bits0; br.n = n0;
+         apply_corrections(blk, corr, al);
+         return ac_refine_walk(br, t, blk, skip, idx);
+      }
+      const unsigned T = (unsigned)__builtin_ctzll(sel);
+      corr |= take_corrections(br, nz & from & ((1ull << T) - 1));
+      if (s != 0xF0) blk[T] = (int16_t)((sb ? 1 : -1) * (1 << al));
+      idx = T + 1;
+   }
+   apply_corrections(blk, corr, al);
+   return rc;
+}
+
+__attribute__((target("bmi2,popcnt")))
+static void refine_band_bmi2(FastBits &br, int16_t *blk, uint64_t band, unsigned al) {
+   apply_corrections(blk, take_corrections(br, nonzero_mask(blk) & band), al);
+}
+#endif
+
 // correction_eob (src/vld.c:228-238): one correction bit for every non-zero coefficient up to Se
 template <class R>
 int Decoder::refine_to_band_end(R &br, int16_t *blk, unsigned idx) {
    if constexpr (!R::kChecked) {                              // no read can fail: visit the non-zero coefficients only
-      if (idx <= se) correct_positions(br, blk, nonzero_mask(blk) & (~0ull << idx) & (~0ull >> (63 - se)), al);
+      if (idx > se) return 0;
+      const uint64_t band = (~0ull << idx) & (~0ull >> (63 - se));
+#if defined(JFE_HAVE_BMI2_PATH)
+      if (br.br.bmi2) { refine_band_bmi2(br, blk, band, al); return 0; }
+#endif
+      correct_positions(br, blk, nonzero_mask(blk) & band, al);
       return 0;
    }
    for (; idx <= se; idx++) {
@@ -646,6 +757,9 @@ int Decoder::ac_refine(R &br, const HuffTable &t, int16_t *blk, uint16_t &skip) 
    if constexpr (R::kChecked) {
       return ac_refine_walk(br, t, blk, skip, ss);
    } else {
+#if defined(JFE_HAVE_BMI2_PATH)
+      if (br.br.bmi2) return ac_refine_bmi2(br, t, blk, skip);
+#endif
       unsigned idx = ss;
       const uint64_t nz = nonzero_mask(blk);                  // coefficients this block places itself lie below idx and are never met again
       while (idx <= se) {
@@ -1051,7 +1165,7 @@ int Decoder::decode_scan() {
 
 }  // namespace jpegfe
 
-// Test hook: decode every block with the reader that checks for the end of the scan on every read (the form that mirrors
-// the reference's read_bit line by line); tests compare it with the default, in which only the last 256 bytes of a scan
-// are decoded that way.
-extern "C" void jpeggpu_internal_vld_force_checked(int on) { jpegfe::g_force_checked.store(on != 0); }
+// Test hook.  mode 1: decode every block with the reader that checks for the end of the scan on every read (the form that
+// mirrors the reference's read_bit line by line); tests compare it with the default (0), in which only the last 256 bytes
+// of a scan are decoded that way.  mode 2: the default without the BMI2 form of the refinement scans.
+extern "C" void jpeggpu_internal_vld_force_checked(int mode) { jpegfe::g_vld_mode.store(mode); }

@@ -33,11 +33,13 @@ struct HuffTable {
 
 struct Component { uint8_t idc = 0, hs = 0, vs = 0, idhdc = 0, idhac = 0, idq = 0; };
 
+struct FastBits;
 struct BitReader {
    const uint8_t *buf = nullptr;   // un-stuffed scan bytes + the marker's 0xFF + zero guard
    uint64_t pos = 0;               // bits consumed
    uint64_t limit = 0;             // consuming bit <limit-1> (the 8th bit of the marker's 0xFF) is an error
    bool fast_allowed = true;       // blocks far from the end of the scan may use the unchecked reader (frontend.cpp FastBits)
+   bool bmi2 = false;              // ... and the PDEP form of the refinement scans (x86-64 with BMI2, found at run time)
 };
 
 struct Decoder {
@@ -110,6 +112,7 @@ struct Decoder {
    template <class R> int ac_first(R &r, const HuffTable &t, int16_t *blk, uint16_t &skip, const uint16_t *q);
    template <class R> int ac_refine(R &r, const HuffTable &t, int16_t *blk, uint16_t &skip);
    template <class R> int ac_refine_walk(R &r, const HuffTable &t, int16_t *blk, uint16_t &skip, unsigned idx);
+   int ac_refine_bmi2(FastBits &r, const HuffTable &t, int16_t *blk, uint16_t &skip);
    template <class R> int refine_to_band_end(R &r, int16_t *blk, unsigned idx);
 };
 

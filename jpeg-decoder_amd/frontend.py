@@ -53,9 +53,10 @@ lib.jpeggpu_internal_vld_force_checked.argtypes = [C.c_int]
 lib.jpeggpu_internal_vld_force_checked.restype = None
 
 
-def vld_force_checked(on):
-    """Test hook: entropy-decode every block with the reader that checks for the end of the scan at every read."""
-    lib.jpeggpu_internal_vld_force_checked(1 if on else 0)
+def vld_force_checked(mode):
+    """Test hook: 1/True = entropy-decode every block with the reader that checks for the end of the scan at every read,
+    2 = the default readers without the BMI2 form of the refinement scans, 0/False = default."""
+    lib.jpeggpu_internal_vld_force_checked(int(mode))
 
 
 class Jpeg:

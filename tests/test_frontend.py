@@ -218,8 +218,9 @@ def test_render_needs_a_gpu():
 
 
 def test_front_end_survives_damaged_files(tmp_path):
-    """tools/fuzz_frontend.cpp under AddressSanitizer + UBSan: 40 000 randomly damaged variants of the
-    fixtures, every scan decoded -- no invalid access, no hang, only status codes."""
+    """tools/fuzz_frontend.cpp under AddressSanitizer + UBSan: 24 000 randomly damaged variants of the
+    fixtures, every scan decoded -- no invalid access, no hang, only status codes; and each variant decoded three ways
+    (default readers, the same without BMI2, the checked reader everywhere) with equal status, message and coefficients."""
     import shutil
     import subprocess
     if shutil.which("g++") is None:
@@ -229,7 +230,7 @@ def test_front_end_survives_damaged_files(tmp_path):
                            "-I" + os.path.join(helpers.ROOT, "jpeg-decoder_amd", "csrc"), "-I" + os.path.join(helpers.ROOT, "include"),
                            "-o", str(exe), os.path.join(helpers.ROOT, "tools", "fuzz_frontend.cpp"),
                            os.path.join(helpers.ROOT, "jpeg-decoder_amd", "csrc", "frontend.cpp")])
-    r = subprocess.run([str(exe), JDIR, "40000"], capture_output=True, text=True, timeout=300,
+    r = subprocess.run([str(exe), JDIR, "24000"], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="halt_on_error=1"))
-    assert r.returncode == 0 and "iterations 40000" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
-    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
+    assert r.returncode == 0 and "iterations 24000" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr and "MISMATCH" not in r.stdout

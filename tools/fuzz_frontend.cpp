@@ -2,9 +2,9 @@
 // truncation, insertions, deletions) on the files of a directory, every scan decoded.  Build with
 //   g++ -O1 -g -std=c++17 -fsanitize=address,undefined -Ijpeg-decoder_amd/csrc -Iinclude tools/fuzz_frontend.cpp jpeg-decoder_amd/csrc/frontend.cpp
 // usage: fuzz <dir> <iterations>.  300 000 iterations over tests/golden/jpeg: no sanitizer finding, no hang.
-// Every variant is decoded twice: as shipped (blocks far from the end of a scan go through the unchecked register
-// bit reader and the bit-map refinement) and with every block through the checked reader that mirrors the
-// reference's read_bit; status, message and every coefficient of the two must be equal.
+// Every variant is decoded three times: as shipped (blocks far from the end of a scan go through the unchecked register
+// bit reader and the bit-map refinement, with PDEP where the CPU has BMI2), the same without BMI2, and with every block
+// through the checked reader that mirrors the reference's read_bit; status, message and every coefficient must be equal.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -14,10 +14,10 @@
 #include "frontend.hpp"
 static uint64_t s = 88172645463325252ull;
 static uint64_t rnd() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
-extern "C" void jpeggpu_internal_vld_force_checked(int on);
+extern "C" void jpeggpu_internal_vld_force_checked(int mode);   // 0 default, 1 checked reader everywhere, 2 default without BMI2
 struct Result { int rc = 0; std::string err; std::vector<std::vector<int16_t>> planes; long scans = 0; uint32_t rows = 0; };
-static Result decode(const std::vector<uint8_t> &b, bool dequant, bool checked) {
-   jpeggpu_internal_vld_force_checked(checked);
+static Result decode(const std::vector<uint8_t> &b, bool dequant, int mode) {
+   jpeggpu_internal_vld_force_checked(mode);
    Result r; r.planes.resize(3);
    jpegfe::Decoder dec; dec.data = b.data(); dec.len = b.size();
    int rc = dec.open();
@@ -54,12 +54,14 @@ int main(int argc, char **argv) {
          case 4: if (b.size() > 10) { size_t p = rnd() % (b.size() - 4); b.erase(b.begin() + p); } break;
          }
       }
-      const Result fast = decode(b, (it & 2) != 0, false), ref = decode(b, (it & 2) != 0, true);
-      if (fast.rc != ref.rc || fast.err != ref.err || fast.planes != ref.planes || fast.scans != ref.scans || fast.rows != ref.rows) {
-         printf("MISMATCH at iteration %ld: rc %d / %d, '%s' / '%s', scans %ld / %ld\n", it, fast.rc, ref.rc, fast.err.c_str(), ref.err.c_str(), fast.scans, ref.scans);
-         FILE *f = fopen("fuzz_mismatch.jpg", "wb"); if (f) { fwrite(b.data(), 1, b.size(), f); fclose(f); }
-         return 1;
-      }
+      const Result fast = decode(b, (it & 2) != 0, 0), ref = decode(b, (it & 2) != 0, 1), plain = decode(b, (it & 2) != 0, 2);
+      for (const Result *o : { &fast, &plain })
+         if (o->rc != ref.rc || o->err != ref.err || o->planes != ref.planes || o->scans != ref.scans || o->rows != ref.rows) {
+            printf("MISMATCH (%s) at iteration %ld: rc %d / %d, '%s' / '%s', scans %ld / %ld\n", o == &fast ? "default" : "no BMI2", it, o->rc, ref.rc,
+                   o->err.c_str(), ref.err.c_str(), o->scans, ref.scans);
+            FILE *f = fopen("fuzz_mismatch.jpg", "wb"); if (f) { fwrite(b.data(), 1, b.size(), f); fclose(f); }
+            return 1;
+         }
       const int rc = fast.rc; scans += fast.scans;
       if (rc == 0) ok++;
       hist[rc < 0 ? 63 : (rc > 62 ? 62 : rc)]++;
