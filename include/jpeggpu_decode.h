@@ -63,7 +63,7 @@ int  jpeggpu_jpeg_open_memory(const uint8_t *data, size_t len, jpeggpu_jpeg_t **
 int  jpeggpu_jpeg_open_file(const char *path, jpeggpu_jpeg_t **out);
 /* Closes the handle.  Its pinned and device buffers are kept for the next file that needs buffers of exactly those
  * sizes (a fresh pinned buffer costs 0.1-0.3 ms per MB when the CPU first touches it), up to JPEGGPU_POOL_BYTES per
- * kind (environment, read once; default 1 GiB, 0 = keep nothing); jpeggpu_shutdown() frees them.                   */
+ * kind (environment, read once; default 2 GiB, 0 = keep nothing); jpeggpu_shutdown() frees them.                   */
 void jpeggpu_jpeg_close(jpeggpu_jpeg_t *j);
 
 int  jpeggpu_jpeg_frame_desc(const jpeggpu_jpeg_t *j, jpeggpu_frame_desc_t *desc);   /* apply_iquant = 1 */

@@ -4,8 +4,8 @@
 //   thread pool : image i of the chunk -> Decoder on the caller's bytes, planes = its slot of the pinned
 //                 chunk buffer (frame-major per component, the layout of jpeggpu_backend_run_batch_device)
 //   main thread : chunk k decoded -> H2D, kernel, D2H queued on stream k%2 -> decode chunk k+1 meanwhile
-//   output      : the caller's raster array is pinned in place (hipHostRegister) so the D2H lands there
-//                 directly; if that is refused, a pinned staging buffer and a parallel memcpy are used.
+//   output      : a raster array that is pinned already (jpeggpu_host_alloc) or can be pinned in place
+//                 (hipHostRegister) receives the D2H directly; else a pinned staging buffer and a parallel memcpy.
 #include <hip/hip_runtime_api.h>
 
 #include <atomic>
@@ -25,6 +25,8 @@
 extern "C" void jpeggpu_internal_set_error(const char *msg);
 extern "C" int jpeggpu_internal_ensure_init(void);
 extern "C" int jpeggpu_internal_device(void);
+extern "C" void *jpeggpu_internal_pool_take(int host, size_t bytes, int device);   // decode_api.cpp: buffers kept between calls
+extern "C" void jpeggpu_internal_pool_give(int host, void *p, size_t bytes, int device);
 
 namespace {
 
@@ -44,26 +46,44 @@ int bfail(int code, const char *msg) { jpeggpu_internal_set_error(msg); return c
       }                                                                         \
    } while (0)
 
-// Everything the pipeline allocates; released whatever way the call ends.
+// Everything the pipeline allocates; released whatever way the call ends.  The chunk buffers go back to the library's
+// buffer cache (decode_api.cpp): a second batch of the same shape finds them there, touched and mapped -- 600 MB of
+// fresh pinned memory cost 0.1-0.3 ms per MB at the first CPU write (profiles/r02_probe_alloc.txt).
 struct Resources {
    uint8_t *h_in[2] = { nullptr, nullptr }, *h_out[2] = { nullptr, nullptr };
    void *d_in[2] = { nullptr, nullptr }, *d_out[2] = { nullptr, nullptr };
+   size_t in_cap = 0, out_cap = 0;
+   int device = -1;
    hipStream_t st[2] = { nullptr, nullptr };
    hipEvent_t ev_done[2] = { nullptr, nullptr };
    void *registered = nullptr;
+   hipError_t host_alloc(uint8_t **p, size_t bytes) {
+      if ((*p = (uint8_t *)jpeggpu_internal_pool_take(1, bytes, device))) return hipSuccess;
+      return hipHostMalloc((void **)p, bytes, hipHostMallocDefault);
+   }
+   hipError_t dev_alloc(void **p, size_t bytes) {
+      if ((*p = jpeggpu_internal_pool_take(0, bytes, device))) return hipSuccess;
+      return hipMalloc(p, bytes);
+   }
    ~Resources() {
       for (int b = 0; b < 2; b++) if (st[b]) (void)hipStreamSynchronize(st[b]);
       if (registered) (void)hipHostUnregister(registered);
       for (int b = 0; b < 2; b++) {
-         if (h_in[b]) (void)hipHostFree(h_in[b]);
-         if (h_out[b]) (void)hipHostFree(h_out[b]);
-         if (d_in[b]) (void)hipFree(d_in[b]);
-         if (d_out[b]) (void)hipFree(d_out[b]);
+         jpeggpu_internal_pool_give(1, h_in[b], in_cap, device);
+         jpeggpu_internal_pool_give(1, h_out[b], out_cap, device);
+         jpeggpu_internal_pool_give(0, d_in[b], in_cap, device);
+         jpeggpu_internal_pool_give(0, d_out[b], out_cap, device);
          if (ev_done[b]) (void)hipEventDestroy(ev_done[b]);
          if (st[b]) (void)hipStreamDestroy(st[b]);
       }
    }
 };
+
+bool pinned_host(const void *p) {
+   hipPointerAttribute_t a;
+   if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+   return a.type == hipMemoryTypeHost;
+}
 
 bool same_geometry(const jpeggpu_frame_desc_t &a, const jpegfe::Decoder &d) {
    if (a.width != d.width || a.height != d.height || a.nbcomp != d.nbcomp) return false;
@@ -188,20 +208,25 @@ extern "C" int jpeggpu_decode_batch(const jpeggpu_blob_t *jpegs, size_t n, uint8
       Pool pool(T);
       bool queued[2] = { false, false };
       size_t queued_base[2] = { 0, 0 }, queued_cnt[2] = { 0, 0 };
+      R.device = jpeggpu_internal_device();
+      R.in_cap = F * in_bytes; R.out_cap = F * out_bytes;
       for (int b = 0; b < nbuf; b++) {
-         HIP_TRYB(hipHostMalloc((void **)&R.h_in[b], F * in_bytes, hipHostMallocDefault));
-         HIP_TRYB(hipMalloc(&R.d_in[b], F * in_bytes));
-         HIP_TRYB(hipMalloc(&R.d_out[b], F * out_bytes));
+         HIP_TRYB(R.host_alloc(&R.h_in[b], R.in_cap));
+         HIP_TRYB(R.dev_alloc(&R.d_in[b], R.in_cap));
+         HIP_TRYB(R.dev_alloc(&R.d_out[b], R.out_cap));
          HIP_TRYB(hipStreamCreateWithFlags(&R.st[b], hipStreamNonBlocking));
          HIP_TRYB(hipEventCreateWithFlags(&R.ev_done[b], hipEventDisableTiming));
       }
-      // pin the caller's raster array in place; otherwise stage
-      if (raster_frame_stride == out_bytes && hipHostRegister(rasters, n * raster_frame_stride, hipHostRegisterDefault) == hipSuccess) {
+      // the caller's raster array: already pinned (jpeggpu_host_alloc, hipHostMalloc) -> the downloads land there; else
+      // pin it in place; where the driver refuses that, stage
+      if (raster_frame_stride == out_bytes && pinned_host(rasters)) {
+         registered = true;
+      } else if (raster_frame_stride == out_bytes && hipHostRegister(rasters, n * raster_frame_stride, hipHostRegisterDefault) == hipSuccess) {
          R.registered = rasters;
          registered = true;
       } else {
          (void)hipGetLastError();
-         for (int b = 0; b < nbuf; b++) HIP_TRYB(hipHostMalloc((void **)&R.h_out[b], F * out_bytes, hipHostMallocDefault));
+         for (int b = 0; b < nbuf; b++) HIP_TRYB(R.host_alloc(&R.h_out[b], R.out_cap));
       }
       // Iteration k runs ONE fork-join over the pool: the decode tasks of chunk k followed by the copy-out
       // tasks of chunk k-1 (staging only).  The copy tasks sit at the end of the list, so the threads reach

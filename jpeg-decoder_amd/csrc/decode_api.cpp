@@ -82,15 +82,16 @@ int report(jpeggpu_jpeg *j, int rc) {
 // A fresh pinned buffer costs little to allocate but 0.1-0.3 ms per MB when the CPU first touches it (page faults:
 // 30 ms for the planes of a 4096x4096 4:4:4 file, profiles/r02_probe_alloc.txt), against 1 ms to clear one that has been
 // touched before.  A closed file's buffers (pinned planes and raster, device planes and raster) are therefore kept, up
-// to JPEGGPU_POOL_BYTES per kind (default 1 GiB, 0 = keep nothing), and handed to the next file that needs one of
+// to JPEGGPU_POOL_BYTES per kind (default 2 GiB, 0 = keep nothing), and handed to the next file that needs one of
 // exactly that size on the same device -- the serving pattern of many files of one geometry.  jpeggpu_shutdown frees them.
+// jpeggpu_decode_batch (batch_api.cpp) keeps its chunk buffers the same way.
 struct Cached { void *p; size_t bytes; int device; bool host; };
 std::mutex g_pool_mu;
 std::vector<Cached> g_pool;                 // oldest first
 size_t g_pool_held[2] = { 0, 0 };           // [host]
 
 size_t pool_limit() {
-   static const size_t v = [] { const char *e = getenv("JPEGGPU_POOL_BYTES"); return e ? (size_t)atoll(e) : ((size_t)1 << 30); }();
+   static const size_t v = [] { const char *e = getenv("JPEGGPU_POOL_BYTES"); return e ? (size_t)atoll(e) : ((size_t)2 << 30); }();
    return v;
 }
 
@@ -317,6 +318,10 @@ std::string out_name(const char *filepath, const char *outfile, uint8_t nbcomp, 
 }  // namespace
 
 extern "C" {
+
+// batch_api.cpp
+void *jpeggpu_internal_pool_take(int host, size_t bytes, int device) { return pool_take(host != 0, bytes, device); }
+void jpeggpu_internal_pool_give(int host, void *p, size_t bytes, int device) { pool_give(host != 0, p, bytes, device); }
 
 // jpeggpu_shutdown (capi.cpp): nothing of the cache outlives the library's default context
 void jpeggpu_internal_pool_drain(void) {
