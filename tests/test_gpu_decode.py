@@ -200,3 +200,40 @@ def test_per_scan_hand_off_uploads_the_dirty_band(gpu):
         else:            # AC scan: one component's whole plane
             assert up in plane_bytes, (ss, se, up)
     assert sum(1 for s in scans if s[1] == 0) >= 2      # Pillow's script has a DC refinement scan
+
+
+def test_handles_on_several_threads_share_the_buffer_cache(gpu):
+    """Four threads open, decode, render and close files of a few geometries over and over (each handle on its own
+    stream; closed handles hand their pinned and device buffers to the next one of the same size, decode_api.cpp).
+    Every image of every pass equals the reference's."""
+    import threading
+    from jpeg_decoder_amd import frontend as F
+    names = ["c4_prog422_160x120.jpg", "prog_420_128x96_q60.jpg", "base_444_61x47_q80.jpg", "prog_444_61x47_q80.jpg",
+             "base_420_61x47_q80.jpg", "ref_shaun_the_sheep.jpeg", "base_gray_61x47_q80.jpg"]
+    blobs = {n: open(os.path.join(JDIR, n), "rb").read() for n in names}
+    want = {n: expected_images(EXPECT[n]) for n in names}
+    errors = []
+
+    def worker(t):
+        try:
+            for rep in range(6):
+                for n in names[t % 2::1 + t % 2]:       # overlapping subsets, different orders of sizes per thread
+                    j = F.Jpeg(blobs[n])
+                    d = j.desc
+                    imgs = []
+                    while not j.eoi:
+                        j.decode_scan()
+                        imgs.append(F.pnm_header(d) + j.render().tobytes())
+                        if j.eoi:
+                            break
+                        j.next_header()
+                    j.close()
+                    got = [hashlib.sha256(b).hexdigest() for b in imgs]
+                    assert got == want[n], (t, rep, n)
+        except BaseException as e:   # noqa: BLE001  (reported by the main thread)
+            errors.append((t, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
