@@ -558,22 +558,33 @@ int Decoder::ac_first(R &r, const HuffTable &t, int16_t *blk, uint16_t &skip, co
    const unsigned last = se;
    while (idx <= last) {
       const uint64_t w = r.window();                         // >= 56 valid bits
+      if (const int32_t e = t.acfast[w >> 54]) {             // code and value bits within 10 bits: run, length and value in one look-up
+         r.skip((unsigned)e & 0xFF);
+         if (!r.ok()) return fail(JPEGGPU_ERR_0XFF00, "%s", kMsgFF);
+         idx += ((unsigned)e >> 8) & 15;
+         if (idx > 63) return fail(JPEGGPU_ERR_UNSUPPORTED, "coefficient AC hors du bloc (indice %u)", idx);
+         int c = (e >> 16) * (1 << al);
+         if (q) c = (int16_t)c * (int)q[idx];
+         blk[idx] = (int16_t)c;
+         idx++;
+         continue;
+      }
       const unsigned f = t.fast[w >> 55];
-      unsigned len;
+      unsigned clen;
       int s;
       if (f) {
-         len = f >> 8;
+         clen = f >> 8;
          s = (int)(f & 0xFF);
       } else {
          const uint32_t w16 = (uint32_t)(w >> 48);
          int nd = t.deep[w >> 55];
-         len = 9;
+         clen = 9;
          if (t.nodes[nd].child[0] < 0) return fail(JPEGGPU_ERR_HUFF_BAD, "[DHT] table de Huffman AC vide");
-         while (t.nodes[nd].child[0] >= 0 && len < 16) { nd = t.nodes[nd].child[(w16 >> (15 - len)) & 1]; len++; }
+         while (t.nodes[nd].child[0] >= 0 && clen < 16) { nd = t.nodes[nd].child[(w16 >> (15 - clen)) & 1]; clen++; }
          if (t.nodes[nd].child[0] >= 0) return fail(JPEGGPU_ERR_HUFF_BAD, "[DHT] table de Huffman AC vide");
          s = t.nodes[nd].sym;
       }
-      r.skip(len);
+      r.skip(clen);
       if (!r.ok()) return fail(JPEGGPU_ERR_0XFF00, "%s", kMsgFF);
       if (s == 0xF0) { idx += 16; continue; }
       const unsigned alpha = (unsigned)s >> 4, gamma = (unsigned)s & 15;
@@ -588,7 +599,7 @@ int Decoder::ac_first(R &r, const HuffTable &t, int16_t *blk, uint16_t &skip, co
       }
       idx += alpha;
       if (gamma > 10) return fail(JPEGGPU_ERR_AC_BAD, "La magnitude doit être inférieur ou égale à 10");
-      const uint32_t v = (uint32_t)((w << len) >> (64 - gamma));   // len + gamma <= 26 bits of the window
+      const uint32_t v = (uint32_t)((w << clen) >> (64 - gamma));   // clen + gamma <= 26 bits of the window
       r.skip(gamma);
       if (!r.ok()) return fail(JPEGGPU_ERR_0XFF00, "%s", kMsgFF);
       if (idx > 63) return fail(JPEGGPU_ERR_UNSUPPORTED, "coefficient AC hors du bloc (indice %u)", idx);   // the reference writes past the block
