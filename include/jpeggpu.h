@@ -168,14 +168,27 @@ int jpeggpu_backend_run_batch_device(const jpeggpu_frame_desc_t *desc, uint32_t 
                                      void *d_out, size_t out_stride, size_t out_frame_stride,
                                      void *hip_stream);
 
+/* The batch in host memory (BASELINE.json configs[4] handed over the way the reference holds its planes, src/progressive.c:73-84):
+ * synchronous like jpeggpu_backend_run, and ONE pipeline over the stripes of all frames, so the upload of a frame
+ * overlaps the kernel and the download of the frame before it (a loop of jpeggpu_backend_run calls cannot: each call
+ * ends with its own download).  Strides as above, in bytes, 0 = densely packed.                                       */
+int jpeggpu_backend_run_batch(const jpeggpu_frame_desc_t *desc, uint32_t nframes,
+                              const jpeggpu_blocl16_t *const coef[3], const size_t coef_frame_stride[3],
+                              const jpeggpu_qtable_t *const qtables[4],
+                              uint8_t *out, size_t out_stride, size_t out_frame_stride);
+
 /* Blocks until everything queued on <hip_stream> (NULL = library stream) has finished.         */
 int jpeggpu_synchronize(void *hip_stream);
 
-/* The same four calls on a context of the caller's (replacing the same reference loop,
+/* The same five calls on a context of the caller's (replacing the same reference loop,
  * src/progressive.c:257-312 / src/baseline.c:160-217); hip_stream == NULL means the context's stream.  */
 int jpeggpu_ctx_backend_run(jpeggpu_ctx_t *ctx, const jpeggpu_frame_desc_t *desc,
                             const jpeggpu_blocl16_t *const coef[3], const jpeggpu_qtable_t *const qtables[4],
                             uint8_t *out, size_t out_stride);
+int jpeggpu_ctx_backend_run_batch(jpeggpu_ctx_t *ctx, const jpeggpu_frame_desc_t *desc, uint32_t nframes,
+                                  const jpeggpu_blocl16_t *const coef[3], const size_t coef_frame_stride[3],
+                                  const jpeggpu_qtable_t *const qtables[4],
+                                  uint8_t *out, size_t out_stride, size_t out_frame_stride);
 int jpeggpu_ctx_backend_run_device(jpeggpu_ctx_t *ctx, const jpeggpu_frame_desc_t *desc,
                                    const void *const d_coef[3], const jpeggpu_qtable_t *const qtables[4],
                                    void *d_out, size_t out_stride, void *hip_stream);

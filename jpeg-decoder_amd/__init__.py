@@ -6,7 +6,7 @@ Thin ctypes binding over the C ABI in include/jpeggpu.h (libjpeggpu.so).  The di
 from .backend import (  # noqa: F401
     JpegGpuError, FrameDesc, Component, make_desc, lib, lib_path, last_error,
     init, shutdown, synchronize, plane_blocks, raster_rows, raster_row_bytes,
-    backend_run, backend_run_device, backend_run_batch_device,
+    backend_run, backend_run_batch, backend_run_device, backend_run_batch_device,
     iquant_blocks, izz_blocks, idct_opt_blocks, ycc2rgb_pixels,
     idct_blocks, idct_coef_table, set_idct_fast, get_idct_fast,
     Context, multi_backend_run, multi_backend_run_batch, reload_tuning, host_register, host_unregister, PinnedArray,

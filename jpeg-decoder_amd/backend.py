@@ -101,6 +101,8 @@ lib.jpeggpu_ctx_synchronize.argtypes = [_vp, _vp]
 lib.jpeggpu_multi_backend_run.argtypes = [C.POINTER(_vp), C.c_int, C.POINTER(FrameDesc), C.POINTER(_vp), C.POINTER(_vp), _vp, _sz]
 lib.jpeggpu_multi_backend_run_batch.argtypes = [C.POINTER(_vp), C.c_int, C.POINTER(FrameDesc), C.c_uint32, C.POINTER(_vp), C.POINTER(_sz),
                                                 C.POINTER(_vp), _vp, _sz, _sz]
+lib.jpeggpu_backend_run_batch.argtypes = [C.POINTER(FrameDesc), C.c_uint32, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_vp), _vp, _sz, _sz]
+lib.jpeggpu_ctx_backend_run_batch.argtypes = [_vp, C.POINTER(FrameDesc), C.c_uint32, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_vp), _vp, _sz, _sz]
 lib.jpeggpu_host_alloc.argtypes = [_sz]
 lib.jpeggpu_host_alloc.restype = _vp
 lib.jpeggpu_host_free.argtypes = [_vp]
@@ -259,6 +261,27 @@ def multi_backend_run(ctxs, desc, coef, qtables, out=None, out_stride=0):
     hs = (_vp * len(ctxs))(*[c.handle for c in ctxs])
     _check(lib.jpeggpu_multi_backend_run(hs, len(ctxs), C.byref(desc), cp, qp, out.ctypes.data, out_stride))
     return out[:rows, :stride]
+
+
+def backend_run_batch(desc, nframes, coef, qtables, out=None, out_stride=0, out_frame_stride=0, coef_frame_stride=None, ctx=None):
+    """jpeggpu_backend_run_batch / jpeggpu_ctx_backend_run_batch: host memory, coef[c] = frame-major int16 array (frame f of plane
+    c at byte offset f * coef_frame_stride[c], default dense); returns (nframes, rows, row_bytes) uint8 (or fills <out>).  Arrays
+    are used where they lie (no copy) when they are C-contiguous int16 / uint8 -- pinned arrays stay pinned."""
+    planes = [coef[c] if (coef[c].dtype == np.int16 and coef[c].flags["C_CONTIGUOUS"]) else np.ascontiguousarray(coef[c], dtype=np.int16)
+              for c in range(desc.nbcomp)]
+    cp = (_vp * 3)(*([a.ctypes.data for a in planes] + [None] * (3 - len(planes))))
+    fs = None
+    if coef_frame_stride is not None:
+        fs = (_sz * 3)(*(list(coef_frame_stride) + [0] * (3 - len(coef_frame_stride))))
+    qp, keep = _qt_array(qtables)
+    rows, rb = raster_rows(desc), raster_row_bytes(desc)
+    if out is None:
+        out = np.zeros((nframes, rows, out_stride or rb), dtype=np.uint8)
+    if ctx is not None:
+        _check(lib.jpeggpu_ctx_backend_run_batch(ctx.handle, C.byref(desc), nframes, cp, fs, qp, out.ctypes.data, out_stride, out_frame_stride))
+    else:
+        _check(lib.jpeggpu_backend_run_batch(C.byref(desc), nframes, cp, fs, qp, out.ctypes.data, out_stride, out_frame_stride))
+    return out
 
 
 def multi_backend_run_batch(ctxs, desc, nframes, coef, qtables):

@@ -6,6 +6,7 @@
 // produces data needs a HIP device.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
@@ -25,11 +26,13 @@ using namespace jpeggpu_k;
 
 // One context per device and caller: its own stream, staging and option.  The process-wide entry points
 // of the header (jpeggpu_backend_run ...) run on a default context bound by jpeggpu_init().
+constexpr int kEventRing = 32;   // events of the host-pointer pipeline: recorded again only long after their unit has finished
+
 struct jpeggpu_ctx_s {
    int device = -1;
    hipStream_t stream = nullptr;                 // default stream of the context (device-pointer forms with hip_stream == NULL)
    hipStream_t pipe[2] = { nullptr, nullptr };   // host-pointer pipeline: [0] uploads, [1] kernels and downloads
-   hipEvent_t up_done[2] = { nullptr, nullptr }, pipe_done[2] = { nullptr, nullptr };   // per stripe parity: uploaded / downloaded
+   hipEvent_t up_done[kEventRing] = {}, pipe_done[kEventRing] = {};   // unit k % kEventRing: uploaded / downloaded
    std::mutex mu;                                // host-pointer and stage-level entries: they share the staging below
    void *d_in = nullptr;  size_t d_in_cap = 0;
    void *d_out = nullptr; size_t d_out_cap = 0;
@@ -42,6 +45,9 @@ struct jpeggpu_ctx_s {
 };
 
 namespace {
+
+constexpr size_t kDeviceStagingBytes = (size_t)1 << 30;   // device-side staging of one host-pointer call (run_host)
+constexpr uint32_t kPipeDepth = 3;                        // units in flight at most
 
 thread_local char g_err[512] = "";
 
@@ -70,6 +76,8 @@ struct Tuning {
    bool no_linear = false;       // JPEGGPU_NO_LINEAR: tiles never run on over the end of an MCU row
    size_t stripe_bytes = 0;      // JPEGGPU_STRIPE_BYTES: stripe size of the host-pointer pipeline
    size_t diag_lds_bytes = 0;    // JPEGGPU_DIAG_LDS_BYTES: larger LDS allocation = fewer resident workgroups per CU
+   size_t staging_bytes = 0;     // JPEGGPU_DEVICE_STAGING_BYTES: device-side staging of one host-pointer call (0 = 1 GiB)
+   uint32_t pipe_depth = 0;      // JPEGGPU_PIPE_DEPTH: units of the host-pointer pipeline in flight at most (0 = default)
 };
 Tuning g_tune;
 std::once_flag g_tune_once;
@@ -82,6 +90,8 @@ void read_tuning() {
    t.no_linear = getenv("JPEGGPU_NO_LINEAR") != nullptr;
    if (const char *e = getenv("JPEGGPU_STRIPE_BYTES")) t.stripe_bytes = (size_t)atoll(e);
    if (const char *e = getenv("JPEGGPU_DIAG_LDS_BYTES")) t.diag_lds_bytes = (size_t)atol(e);
+   if (const char *e = getenv("JPEGGPU_DEVICE_STAGING_BYTES")) t.staging_bytes = (size_t)atoll(e);
+   if (const char *e = getenv("JPEGGPU_PIPE_DEPTH")) t.pipe_depth = (uint32_t)atoi(e);
    g_tune = t;
 }
 const Tuning &tuning() { std::call_once(g_tune_once, read_tuning); return g_tune; }
@@ -102,17 +112,17 @@ int ctx_new(int device, jpeggpu_ctx_s **out) {
    jpeggpu_ctx_s *c = new jpeggpu_ctx_s;
    c->device = device;
    hipError_t rc = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-   for (int i = 0; i < 2 && rc == hipSuccess; i++) {
-      rc = hipStreamCreateWithFlags(&c->pipe[i], hipStreamNonBlocking);
-      if (rc == hipSuccess) rc = hipEventCreateWithFlags(&c->pipe_done[i], hipEventDisableTiming);
+   for (int i = 0; i < 2 && rc == hipSuccess; i++) rc = hipStreamCreateWithFlags(&c->pipe[i], hipStreamNonBlocking);
+   for (int i = 0; i < kEventRing && rc == hipSuccess; i++) {
+      rc = hipEventCreateWithFlags(&c->pipe_done[i], hipEventDisableTiming);
       if (rc == hipSuccess) rc = hipEventCreateWithFlags(&c->up_done[i], hipEventDisableTiming);
    }
    if (rc != hipSuccess) {
-      for (int i = 0; i < 2; i++) {
+      for (int i = 0; i < kEventRing; i++) {
          if (c->pipe_done[i]) (void)hipEventDestroy(c->pipe_done[i]);
          if (c->up_done[i]) (void)hipEventDestroy(c->up_done[i]);
-         if (c->pipe[i]) (void)hipStreamDestroy(c->pipe[i]);
       }
+      for (int i = 0; i < 2; i++) if (c->pipe[i]) (void)hipStreamDestroy(c->pipe[i]);
       if (c->stream) (void)hipStreamDestroy(c->stream);
       delete c;
       return fail(JPEGGPU_ERR_HIP, "stream/event creation on device %d: %s", device, hipGetErrorString(rc));
@@ -136,10 +146,9 @@ void ctx_delete(jpeggpu_ctx_s *c) {
       (void)hipStreamSynchronize(c->pipe[i]);
       if (c->h_in[i]) (void)hipHostFree(c->h_in[i]);
       if (c->h_out[i]) (void)hipHostFree(c->h_out[i]);
-      (void)hipEventDestroy(c->pipe_done[i]);
-      (void)hipEventDestroy(c->up_done[i]);
       (void)hipStreamDestroy(c->pipe[i]);
    }
+   for (int i = 0; i < kEventRing; i++) { (void)hipEventDestroy(c->pipe_done[i]); (void)hipEventDestroy(c->up_done[i]); }
    if (c->d_in) (void)hipFree(c->d_in);
    if (c->d_out) (void)hipFree(c->d_out);
    if (float *t = c->d_slow_coef.load()) (void)hipFree(t);
@@ -351,41 +360,47 @@ bool is_pinned_host(const void *p) {
    return a.type == hipMemoryTypeHost;
 }
 
-// The host-pointer form.  The frame is cut into stripes of whole MCU rows (a stripe is a frame of its own to the
-// kernel: replicate upsampling has no halo, src/decoder_utils.c:72-80).  The link to the host is full duplex
-// (profiles/r02_probe_pcie.txt: 57 GB/s up and 57 GB/s down at the same time), so the uploads of all stripes queue
-// back to back on one stream and nothing else ever sits between them; a second stream takes, per stripe, the wait for
-// that stripe's upload, its kernel and its download.  Upload of stripe k+1, kernel of stripe k and download of stripe
-// k-1 overlap, and the call costs the upload time plus one stripe's kernel and download.  Caller memory that is
-// already pinned (jpeggpu_host_alloc, hipHostMalloc, jpeggpu_host_register) is read and written by the DMA engines in
-// place; pageable memory (the reference's malloc'ed buffers, src/progressive.c:73-84) goes through two pinned stripe
-// buffers per direction, filled and emptied by this thread while the other stripe is in flight.
-int run_host(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, const jpeggpu_blocl16_t *const coef[3], const jpeggpu_qtable_t *const qt[4],
-             uint8_t *out, size_t out_stride) {
+// The host-pointer forms.  Every frame is cut into stripes of whole MCU rows (a stripe is a frame of its own to the
+// kernel: replicate upsampling has no halo, src/decoder_utils.c:72-80); the stripes of all frames of the call form one
+// sequence of units.  The link to the host is full duplex (profiles/r02_probe_pcie.txt: 57 GB/s up and 57 GB/s down
+// at the same time), so the uploads of all units queue back to back on one stream and nothing else ever sits between
+// them; a second stream takes, per unit, the wait for that unit's upload, its kernel and its download.  Upload of unit
+// k+1, kernel of unit k and download of unit k-1 overlap -- across the frames of a batch as well -- and the call costs
+// the upload time plus one unit's kernel and download.  Caller memory that
+// is already pinned (jpeggpu_host_alloc, hipHostMalloc, jpeggpu_host_register) is read and written by the DMA engines
+// in place; pageable memory (the reference's malloc'ed buffers, src/progressive.c:73-84) goes through two pinned
+// buffers per direction, filled and emptied by host threads while the other unit is in flight.
+//
+// Frames first, first + step, ... (count of them) of the caller's arrays: plane c of frame f at coef[c] + f * cfs[c],
+// its raster at out + f * out_frame_stride.
+int run_host(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, uint32_t first, uint32_t step, uint32_t count,
+             const jpeggpu_blocl16_t *const coef[3], const size_t cfs[3], const jpeggpu_qtable_t *const qt[4],
+             uint8_t *out, size_t out_stride, size_t out_frame_stride) {
    const size_t row_bytes = jpeggpu_raster_row_bytes(d), rows = jpeggpu_raster_rows(d);
    if (out_stride == 0) out_stride = row_bytes;
    if (out_stride < row_bytes) return fail(JPEGGPU_ERR_INVALID_ARG, "out_stride %zu < row bytes %zu", out_stride, row_bytes);
+   if (out_frame_stride == 0) out_frame_stride = out_stride * rows;
+   if (count == 0) return 0;
    std::lock_guard<std::mutex> lk(ctx->mu);
-   const int idct_fast = ctx->idct_fast.load();              // one snapshot for every stripe of this frame
+   const int idct_fast = ctx->idct_fast.load();              // one snapshot for every unit of this call
    hipStream_t s_up = ctx->pipe[0], s_down = ctx->pipe[1];
    // whatever way this function is left, nothing may still be copying from / into the caller's memory or the staging
    struct Drain {
       jpeggpu_ctx_s *c; bool armed = true;
       ~Drain() { if (armed) { (void)hipStreamSynchronize(c->pipe[0]); (void)hipStreamSynchronize(c->pipe[1]); } }
    } drain{ ctx };
-   size_t plane_bytes[3] = { 0, 0, 0 }, off[3] = { 0, 0, 0 }, row_in[3] = { 0, 0, 0 }, in_bytes = 0, in_per_mcu_row = 0;
+   size_t fstride[3] = { 0, 0, 0 }, row_in[3] = { 0, 0, 0 }, in_per_mcu_row = 0;
    for (int c = 0; c < d->nbcomp; c++) {
-      plane_bytes[c] = jpeggpu_plane_blocks(d, c) * sizeof(jpeggpu_blocl16_t);
+      fstride[c] = (cfs && cfs[c]) ? cfs[c] : jpeggpu_plane_blocks(d, c) * sizeof(jpeggpu_blocl16_t);
       row_in[c] = (size_t)d->nbmcuH * d->comp[c].hs * d->comp[c].vs * sizeof(jpeggpu_blocl16_t);   // one MCU row of plane c
-      off[c] = in_bytes; in_bytes += plane_bytes[c]; in_per_mcu_row += row_in[c];
+      in_per_mcu_row += row_in[c];
    }
    const size_t band = (size_t)d->max_v * 8;                 // raster rows per MCU row
-   const size_t out_bytes = row_bytes * rows;
-   int rc = grow(&ctx->d_in, &ctx->d_in_cap, in_bytes, false); if (rc) return rc;
-   rc = grow(&ctx->d_out, &ctx->d_out_cap, out_bytes, false); if (rc) return rc;
+   const uint32_t last = first + (count - 1) * step;
    bool in_pinned = true;
-   for (int c = 0; c < d->nbcomp; c++) in_pinned = in_pinned && is_pinned_host(coef[c]);
-   const bool out_pinned = is_pinned_host(out);
+   for (int c = 0; c < d->nbcomp; c++)
+      in_pinned = in_pinned && is_pinned_host((const char *)coef[c] + (size_t)first * fstride[c]) && is_pinned_host((const char *)coef[c] + (size_t)last * fstride[c]);
+   const bool out_pinned = is_pinned_host(out + (size_t)first * out_frame_stride) && is_pinned_host(out + (size_t)last * out_frame_stride);
    // stripe height: ~16 MiB of coefficients when the DMA engines work in place, ~8 MiB when a host thread stages
    // (tools/sweep_stripe.py, profiles/r02_sweep_stripe.txt), at least one MCU row, at most the frame
    const size_t target = tuning().stripe_bytes ? tuning().stripe_bytes : ((size_t)(in_pinned && out_pinned ? 16 : 8) << 20);
@@ -393,91 +408,118 @@ int run_host(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, const jpeggpu_bl
    if (srows < 1) srows = 1;
    if (srows > d->nbmcuV) srows = d->nbmcuV;
    const uint32_t nstripes = (d->nbmcuV + srows - 1) / srows;
-   if (!in_pinned) for (int b = 0; b < 2; b++) { rc = grow(&ctx->h_in[b], &ctx->h_in_cap[b], (size_t)srows * in_per_mcu_row, true); if (rc) return rc; }
-   if (!out_pinned) for (int b = 0; b < 2; b++) { rc = grow(&ctx->h_out[b], &ctx->h_out_cap[b], (size_t)srows * band * row_bytes, true); if (rc) return rc; }
+   if ((uint64_t)nstripes * count > 0xFFFFFFF0ull) return fail(JPEGGPU_ERR_INVALID_ARG, "too many stripes in one call");
+   const uint32_t nunits = nstripes * count;
+   const size_t slot_in = (size_t)srows * in_per_mcu_row, slot_out = (size_t)srows * band * row_bytes;
+   // Device side: every unit of the call has a slot of its own (coefficients + raster band) as long as that stays within
+   // kDeviceStagingBytes; a longer call goes round the slots, and waits for everything queued each time it starts over
+   // (1 GiB of traffic apart: 13 ms of transfers for one drained pipeline).  No finer-grained reuse: an upload stream that
+   // waits for an event of the download stream, or a host that waits inside the queueing loop, halves the throughput
+   // (the two directions stop overlapping; tools/probe_pcie.hip, profiles/r02_probe_pcie.txt).
+   uint32_t nslots = (uint32_t)std::min<size_t>((tuning().staging_bytes ? tuning().staging_bytes : kDeviceStagingBytes) / (slot_in + slot_out), 0x7FFFFFFF);
+   if (nslots < 2) nslots = 2;
+   if (nslots > nunits) nslots = nunits;
+   int rc = grow(&ctx->d_in, &ctx->d_in_cap, nslots * slot_in, false); if (rc) return rc;
+   rc = grow(&ctx->d_out, &ctx->d_out_cap, nslots * slot_out, false); if (rc) return rc;
+   if (!in_pinned) for (int b = 0; b < 2; b++) { rc = grow(&ctx->h_in[b], &ctx->h_in_cap[b], slot_in, true); if (rc) return rc; }
+   if (!out_pinned) for (int b = 0; b < 2; b++) { rc = grow(&ctx->h_out[b], &ctx->h_out_cap[b], slot_out, true); if (rc) return rc; }
 
-   auto copy_out = [&](uint32_t k) {   // staged raster band of stripe k -> the caller's rows
-      const uint32_t m0 = k * srows, n = (m0 + srows <= d->nbmcuV ? srows : d->nbmcuV - m0);
+   uint32_t depth = tuning().pipe_depth ? tuning().pipe_depth : kPipeDepth;
+   if (depth > (uint32_t)kEventRing - 2) depth = kEventRing - 2;
+   struct Unit { uint32_t frame, m0, n; };
+   auto unit = [&](uint32_t k) {
+      const uint32_t fi = k / nstripes, m0 = (k - fi * nstripes) * srows;
+      return Unit{ first + fi * step, m0, (m0 + srows <= d->nbmcuV ? srows : d->nbmcuV - m0) };
+   };
+   auto copy_out = [&](uint32_t k) {   // staged raster band of unit k -> the caller's rows
+      const Unit u = unit(k);
       const uint8_t *src = (const uint8_t *)ctx->h_out[k & 1];
-      uint8_t *dst = out + (size_t)m0 * band * out_stride;
-      if (out_stride == row_bytes) memcpy(dst, src, (size_t)n * band * row_bytes);
-      else for (size_t r = 0; r < (size_t)n * band; r++) memcpy(dst + r * out_stride, src + r * row_bytes, row_bytes);
+      uint8_t *dst = out + (size_t)u.frame * out_frame_stride + (size_t)u.m0 * band * out_stride;
+      if (out_stride == row_bytes) memcpy(dst, src, (size_t)u.n * band * row_bytes);
+      else for (size_t r = 0; r < (size_t)u.n * band; r++) memcpy(dst + r * out_stride, src + r * row_bytes, row_bytes);
    };
    // Pageable output of some size: a second host thread empties the download staging while this one fills the upload
    // staging (one thread copies ~29 GB/s, profiles/r02_sweep_stripe.txt, and would otherwise move in + out = 1.5x
-   // the frame's coefficients by itself).  It lives for this call only and is joined on every way out.
+   // the coefficients by itself).  It lives for this call only and is joined on every way out.
    struct OutCopier {
       std::thread th;
-      std::atomic<uint32_t> enqueued{ 0 }, copied{ 0 };        // stripes whose download is queued / is in the caller's rows
+      std::atomic<uint32_t> enqueued{ 0 }, copied{ 0 };        // units whose download is queued / is in the caller's rows
       std::atomic<int> err{ 0 };
       std::atomic<bool> stop{ false };
       ~OutCopier() { stop.store(true); if (th.joinable()) th.join(); }
    } oc;
-   bool helper = !out_pinned && nstripes >= 3 && out_bytes >= ((size_t)16 << 20);
+   bool helper = !out_pinned && nunits >= 3 && row_bytes * rows * count >= ((size_t)16 << 20);
    if (helper) {
       try {
-         oc.th = std::thread([&, nstripes] {
+         oc.th = std::thread([&, nunits] {
             if (hipSetDevice(ctx->device) != hipSuccess) { oc.err.store((int)hipErrorInvalidDevice); return; }
-            for (uint32_t k = 0; k < nstripes; k++) {
+            for (uint32_t k = 0; k < nunits; k++) {
                while (oc.enqueued.load(std::memory_order_acquire) <= k) { if (oc.stop.load()) return; std::this_thread::yield(); }
-               hipError_t e = hipEventSynchronize(ctx->pipe_done[k & 1]);
+               hipError_t e = hipEventSynchronize(ctx->pipe_done[k % kEventRing]);
                if (e != hipSuccess) { oc.err.store((int)e); return; }
                copy_out(k);
                oc.copied.store(k + 1, std::memory_order_release);
             }
          });
-      } catch (const std::system_error &) { helper = false; }    // no thread to be had: this thread copies, as for small frames
+      } catch (const std::system_error &) { helper = false; }    // no thread to be had: this thread copies, as for small calls
    }
-   // events are used in rings of two: a hipStreamWaitEvent refers to the record that preceded it, recording the event
-   // again for stripe k+2 does not disturb it
-   for (uint32_t k = 0; k < nstripes; k++) {
-      const int b = (int)(k & 1);
-      const uint32_t m0 = k * srows, n = (m0 + srows <= d->nbmcuV ? srows : d->nbmcuV - m0);
-      if (!in_pinned && k >= 2) HIP_TRY(hipEventSynchronize(ctx->up_done[b]));   // stripe k-2 has left this staging buffer
+   // events are used in a ring: a hipStreamWaitEvent refers to the record that preceded it, recording the event again
+   // for a later unit does not disturb it
+   for (uint32_t k = 0; k < nunits; k++) {
+      const int b = (int)(k & 1), e = (int)(k % kEventRing);   // staging buffer, events
+      const uint32_t sl = k % nslots;
+      const Unit u = unit(k);
+      if (!in_pinned && k >= 2) HIP_TRY(hipEventSynchronize(ctx->up_done[(k - 2) % kEventRing]));   // unit k-2 has left this staging buffer
+      if (k != 0 && sl == 0) HIP_TRY(hipStreamSynchronize(s_down));   // the ring starts over: every kernel so far has read its slot
+      // At most <depth> units in flight: the host waits for the download of unit k - depth before it queues unit k.  Measured
+      // (profiles/r02_host_pipeline_depth.txt): with 64 frame-sized units queued as fast as the host can, the enqueue calls
+      // start to block after some 20 units and the whole pipeline falls from 76 to 45 GB/s; depth 2-3 keeps 76.
+      if (k >= depth) HIP_TRY(hipEventSynchronize(ctx->pipe_done[(k - depth) % kEventRing]));
       const void *dc[3] = { nullptr, nullptr, nullptr };
       size_t hoff = 0;
+      char *const d_slot = (char *)ctx->d_in + (size_t)sl * slot_in;
       for (int c = 0; c < d->nbcomp; c++) {
-         const char *src = (const char *)coef[c] + (size_t)m0 * row_in[c];
-         char *dst = (char *)ctx->d_in + off[c] + (size_t)m0 * row_in[c];
+         const char *src = (const char *)coef[c] + (size_t)u.frame * fstride[c] + (size_t)u.m0 * row_in[c];
          if (!in_pinned) {
-            memcpy((char *)ctx->h_in[b] + hoff, src, (size_t)n * row_in[c]);
+            memcpy((char *)ctx->h_in[b] + hoff, src, (size_t)u.n * row_in[c]);
             src = (const char *)ctx->h_in[b] + hoff;
-            hoff += (size_t)n * row_in[c];
          }
-         HIP_TRY(hipMemcpyAsync(dst, src, (size_t)n * row_in[c], hipMemcpyHostToDevice, s_up));
-         dc[c] = dst;
+         HIP_TRY(hipMemcpyAsync(d_slot + hoff, src, (size_t)u.n * row_in[c], hipMemcpyHostToDevice, s_up));
+         dc[c] = d_slot + hoff;
+         hoff += (size_t)u.n * row_in[c];                        // a multiple of 128: the next plane stays 16-byte aligned
       }
-      HIP_TRY(hipEventRecord(ctx->up_done[b], s_up));
-      if (!out_pinned && k >= 2) {                               // stripe k-2 sits in the staging buffer stripe k downloads into
+      HIP_TRY(hipEventRecord(ctx->up_done[e], s_up));
+      if (!out_pinned && k >= 2) {                               // unit k-2 sits in the staging buffer unit k downloads into
          if (helper) {
             while (oc.copied.load(std::memory_order_acquire) < k - 1) {
                if (oc.err.load()) return fail(JPEGGPU_ERR_HIP, "download of a stripe: %s", hipGetErrorString((hipError_t)oc.err.load()));
                std::this_thread::yield();
             }
          } else {
-            HIP_TRY(hipEventSynchronize(ctx->pipe_done[b]));
+            HIP_TRY(hipEventSynchronize(ctx->pipe_done[(k - 2) % kEventRing]));
             copy_out(k - 2);
          }
       }
-      HIP_TRY(hipStreamWaitEvent(s_down, ctx->up_done[b], 0));
+      HIP_TRY(hipStreamWaitEvent(s_down, ctx->up_done[e], 0));
       jpeggpu_frame_desc_t sd = *d;
-      sd.nbmcuV = n;
-      uint8_t *d_band = (uint8_t *)ctx->d_out + (size_t)m0 * band * row_bytes;
+      sd.nbmcuV = u.n;
+      uint8_t *d_band = (uint8_t *)ctx->d_out + (size_t)sl * slot_out;
       rc = run_device(ctx, &sd, 1, dc, nullptr, qt, d_band, row_bytes, 0, s_down, true, idct_fast); if (rc) return rc;
-      if (!out_pinned) HIP_TRY(hipMemcpyAsync(ctx->h_out[b], d_band, (size_t)n * band * row_bytes, hipMemcpyDeviceToHost, s_down));
-      else if (out_stride == row_bytes) HIP_TRY(hipMemcpyAsync(out + (size_t)m0 * band * row_bytes, d_band, (size_t)n * band * row_bytes, hipMemcpyDeviceToHost, s_down));
-      else HIP_TRY(hipMemcpy2DAsync(out + (size_t)m0 * band * out_stride, out_stride, d_band, row_bytes, row_bytes, (size_t)n * band, hipMemcpyDeviceToHost, s_down));
-      HIP_TRY(hipEventRecord(ctx->pipe_done[b], s_down));
+      uint8_t *dst = out + (size_t)u.frame * out_frame_stride + (size_t)u.m0 * band * out_stride;
+      if (!out_pinned) HIP_TRY(hipMemcpyAsync(ctx->h_out[b], d_band, (size_t)u.n * band * row_bytes, hipMemcpyDeviceToHost, s_down));
+      else if (out_stride == row_bytes) HIP_TRY(hipMemcpyAsync(dst, d_band, (size_t)u.n * band * row_bytes, hipMemcpyDeviceToHost, s_down));
+      else HIP_TRY(hipMemcpy2DAsync(dst, out_stride, d_band, row_bytes, row_bytes, (size_t)u.n * band, hipMemcpyDeviceToHost, s_down));
+      HIP_TRY(hipEventRecord(ctx->pipe_done[e], s_down));
       oc.enqueued.store(k + 1, std::memory_order_release);
    }
    if (helper) {
-      oc.th.join();                                           // it has seen every stripe queued, so it runs to the end
+      oc.th.join();                                           // it has seen every unit queued, so it runs to the end
       if (oc.err.load()) return fail(JPEGGPU_ERR_HIP, "download of a stripe: %s", hipGetErrorString((hipError_t)oc.err.load()));
       HIP_TRY(hipStreamSynchronize(s_down));
    } else {
-      // drain, oldest stripe first
-      for (uint32_t k = (nstripes >= 2 ? nstripes - 2 : 0); k < nstripes; k++) {
-         HIP_TRY(hipEventSynchronize(ctx->pipe_done[k & 1]));
+      // drain, oldest unit first
+      for (uint32_t k = (nunits >= 2 ? nunits - 2 : 0); k < nunits; k++) {
+         HIP_TRY(hipEventSynchronize(ctx->pipe_done[k % kEventRing]));
          if (!out_pinned) copy_out(k);
       }
    }
@@ -486,12 +528,20 @@ int run_host(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, const jpeggpu_bl
    return 0;
 }
 
-int ctx_backend_run(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, const jpeggpu_blocl16_t *const coef[3],
-                    const jpeggpu_qtable_t *const qt[4], uint8_t *out, size_t out_stride) {
+int ctx_backend_run_batch(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, uint32_t nframes, const jpeggpu_blocl16_t *const coef[3],
+                          const size_t cfs[3], const jpeggpu_qtable_t *const qt[4], uint8_t *out, size_t out_stride, size_t out_frame_stride) {
    int rc = validate(d, qt); if (rc) return rc;
    if (!out) return fail(JPEGGPU_ERR_INVALID_ARG, "out is NULL");
-   for (int c = 0; c < d->nbcomp; c++) if (!coef || !coef[c]) return fail(JPEGGPU_ERR_INVALID_ARG, "coef[%d] is NULL", c);
-   return run_host(ctx, d, coef, qt, out, out_stride);
+   for (int c = 0; c < d->nbcomp; c++) {
+      if (!coef || !coef[c]) return fail(JPEGGPU_ERR_INVALID_ARG, "coef[%d] is NULL", c);
+      if (cfs && cfs[c] & 15) return fail(JPEGGPU_ERR_INVALID_ARG, "coef_frame_stride[%d] must be a multiple of 16", c);
+   }
+   return run_host(ctx, d, 0, 1, nframes, coef, cfs, qt, out, out_stride, out_frame_stride);
+}
+
+int ctx_backend_run(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, const jpeggpu_blocl16_t *const coef[3],
+                    const jpeggpu_qtable_t *const qt[4], uint8_t *out, size_t out_stride) {
+   return ctx_backend_run_batch(ctx, d, 1, coef, nullptr, qt, out, out_stride, 0);
 }
 
 }  // namespace
@@ -594,6 +644,13 @@ int jpeggpu_ctx_backend_run(jpeggpu_ctx_t *ctx, const jpeggpu_frame_desc_t *d, c
    return ctx_backend_run(ctx, d, coef, qt, out, out_stride);
 }
 
+int jpeggpu_ctx_backend_run_batch(jpeggpu_ctx_t *ctx, const jpeggpu_frame_desc_t *d, uint32_t nframes, const jpeggpu_blocl16_t *const coef[3],
+                                  const size_t coef_frame_stride[3], const jpeggpu_qtable_t *const qt[4], uint8_t *out,
+                                  size_t out_stride, size_t out_frame_stride) {
+   int rc = bind(ctx); if (rc) return rc;
+   return ctx_backend_run_batch(ctx, d, nframes, coef, coef_frame_stride, qt, out, out_stride, out_frame_stride);
+}
+
 // ---- several GPUs from one process: independent shards, one host thread per context, no exchange step ----
 
 // (ii) ONE frame cut into contiguous MCU-row stripes: context g decodes rows [g*nbmcuV/n, (g+1)*nbmcuV/n) of every component
@@ -629,14 +686,13 @@ static int run_sharded(jpeggpu_ctx_t *const *ctxs, int nctx, const jpeggpu_frame
                sd.nbmcuV = m1 - m0;
                const jpeggpu_blocl16_t *sc[3] = { nullptr, nullptr, nullptr };
                for (int c = 0; c < d->nbcomp; c++) sc[c] = (const jpeggpu_blocl16_t *)((const char *)coef[c] + (size_t)m0 * row_in[c]);
-               r = run_host(ctxs[g], &sd, sc, qt, out + (size_t)m0 * band * out_stride, out_stride);
+               r = run_host(ctxs[g], &sd, 0, 1, 1, sc, nullptr, qt, out + (size_t)m0 * band * out_stride, out_stride, 0);
             }
          } else if (!r) {
-            for (uint32_t f = (uint32_t)g; f < nframes && !r; f += (uint32_t)nctx) {
-               const jpeggpu_blocl16_t *fc[3] = { nullptr, nullptr, nullptr };
-               for (int c = 0; c < d->nbcomp; c++) fc[c] = (const jpeggpu_blocl16_t *)((const char *)coef[c] + (size_t)f * cfs[c]);
-               r = run_host(ctxs[g], d, fc, qt, out + (size_t)f * out_frame_stride, out_stride);
-            }
+            // frames g, g + nctx, ...: one pipelined call, so that the upload of a frame overlaps the download of the one before
+            if ((uint32_t)g < nframes)
+               r = run_host(ctxs[g], d, (uint32_t)g, (uint32_t)nctx, (nframes - (uint32_t)g + (uint32_t)nctx - 1) / (uint32_t)nctx, coef, cfs, qt,
+                            out, out_stride, out_frame_stride);
          }
          status[(size_t)g] = r;
          if (r) text[(size_t)g] = g_err;     // g_err is thread-local: carry the text back to the caller's thread
@@ -683,13 +739,19 @@ int jpeggpu_backend_run_device(const jpeggpu_frame_desc_t *d, const void *const 
    return jpeggpu_backend_run_batch_device(d, 1, d_coef, nullptr, qt, d_out, out_stride, 0, hip_stream);
 }
 
-int jpeggpu_backend_run(const jpeggpu_frame_desc_t *d, const jpeggpu_blocl16_t *const coef[3], const jpeggpu_qtable_t *const qt[4],
-                        uint8_t *out, size_t out_stride) {
-   int rc = validate(d, qt); if (rc) return rc;
+int jpeggpu_backend_run_batch(const jpeggpu_frame_desc_t *d, uint32_t nframes, const jpeggpu_blocl16_t *const coef[3],
+                              const size_t coef_frame_stride[3], const jpeggpu_qtable_t *const qt[4], uint8_t *out,
+                              size_t out_stride, size_t out_frame_stride) {
+   int rc = validate(d, qt); if (rc) return rc;           // argument errors are reported without a device
    if (!out) return fail(JPEGGPU_ERR_INVALID_ARG, "out is NULL");
    for (int c = 0; c < d->nbcomp; c++) if (!coef || !coef[c]) return fail(JPEGGPU_ERR_INVALID_ARG, "coef[%d] is NULL", c);
    jpeggpu_ctx_s *c; rc = default_ctx(&c); if (rc) return rc;
-   return run_host(c, d, coef, qt, out, out_stride);
+   return ctx_backend_run_batch(c, d, nframes, coef, coef_frame_stride, qt, out, out_stride, out_frame_stride);
+}
+
+int jpeggpu_backend_run(const jpeggpu_frame_desc_t *d, const jpeggpu_blocl16_t *const coef[3], const jpeggpu_qtable_t *const qt[4],
+                        uint8_t *out, size_t out_stride) {
+   return jpeggpu_backend_run_batch(d, 1, coef, nullptr, qt, out, out_stride, 0);
 }
 
 // The allocation-free variant of jpeggpu_backend_run: same bytes, no hipMalloc / hipFree / hipHostMalloc anywhere on

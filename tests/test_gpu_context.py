@@ -225,3 +225,65 @@ def test_host_pointer_helper_thread(gpu, stripe, mix):
         else:
             os.environ["JPEGGPU_STRIPE_BYTES"] = old
         gpu.reload_tuning()
+
+
+@pytest.mark.parametrize("mem", ["pageable", "pinned"])
+@pytest.mark.parametrize("stripe,staging", [(0, 0), (60000, 0), (60000, 400000)], ids=["default", "60kB_stripes", "60kB_stripes_small_ring"])
+def test_host_pointer_batch(gpu, mem, stripe, staging):
+    """jpeggpu_backend_run_batch: N frames in host memory through ONE pipeline (units = stripes of all frames).  Dense and
+    padded strides (planes, rows, frames), pageable and pinned memory, on the default context and on a context of its
+    own, more units than staging buffers and -- with a small device-side ring -- than device slots; every frame equals
+    the oracle's."""
+    old, old2 = os.environ.get("JPEGGPU_STRIPE_BYTES"), os.environ.get("JPEGGPU_DEVICE_STAGING_BYTES")
+    if stripe:
+        os.environ["JPEGGPU_STRIPE_BYTES"] = str(stripe)
+    if staging:
+        os.environ["JPEGGPU_DEVICE_STAGING_BYTES"] = str(staging)
+    gpu.reload_tuning()
+    held = []
+
+    def place(a):
+        if mem == "pageable":
+            return a
+        h = gpu.PinnedArray(a.shape, a.dtype)
+        h.array[...] = a
+        held.append(h)
+        return h.array
+
+    try:
+        for samp, (w, h), nf in ((((2, 2), (1, 1), (1, 1)), (200, 120), 7), (((1, 1),) * 3, (97, 33), 5), (((1, 1),), (130, 50), 4)):
+            d = helpers.oracle_desc(w, h, samp)
+            gd = helpers.to_gpu_desc(gpu, d)
+            nb = [helpers.plane_shape(d, c)[0] for c in range(d.nbcomp)]
+            pad = 3                                                           # blocks of padding between frames of a plane
+            host = [pyoracle.synth_blocks((nb[c] + pad) * nf, 900 + c).reshape(nf, nb[c] + pad, 64) for c in range(d.nbcomp)]
+            want = [orc.backend_run(d, [host[c][f, :nb[c]] for c in range(d.nbcomp)], QT) for f in range(nf)]
+            rows, rb = want[0].shape
+            for dense in (True, False):
+                if dense:
+                    planes = [place(np.ascontiguousarray(host[c][:, :nb[c]])) for c in range(d.nbcomp)]
+                    cfs, ostride, ofs = None, 0, 0
+                    out = place(np.full((nf, rows, rb), 0xCD, dtype=np.uint8))
+                else:
+                    planes = [place(host[c]) for c in range(d.nbcomp)]
+                    cfs = [(nb[c] + pad) * 128 for c in range(d.nbcomp)]
+                    ostride, ofs = rb + 19, (rows + 2) * (rb + 19)
+                    out = place(np.full((nf, rows + 2, rb + 19), 0xCD, dtype=np.uint8))
+                for ctx in (None, gpu.Context(0)):
+                    for _ in range(2):
+                        out[...] = 0xCD
+                        gpu.backend_run_batch(gd, nf, planes, QT, out=out, out_stride=ostride, out_frame_stride=ofs, coef_frame_stride=cfs, ctx=ctx)
+                        for f in range(nf):
+                            assert np.array_equal(out[f, :rows, :rb], want[f]), (samp, dense, f)
+                        if not dense:
+                            assert np.all(out[:, rows:, :] == 0xCD) and np.all(out[:, :, rb:] == 0xCD)
+                    if ctx is not None:
+                        ctx.close()
+    finally:
+        [h.free() for h in held]
+        for name, val in (("JPEGGPU_STRIPE_BYTES", old), ("JPEGGPU_DEVICE_STAGING_BYTES", old2)):
+            if val is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = val
+        gpu.reload_tuning()

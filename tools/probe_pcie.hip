@@ -10,6 +10,8 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
+__global__ void touch(unsigned *p, unsigned n) { unsigned i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = i; }
+
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 template <class F> static double median_ms(int reps, F &&f) {
@@ -77,6 +79,58 @@ int main() {
          }
          sync_all(); }), IN + OUT);
       for (auto &e : ev) (void)hipEventDestroy(e);
+   }
+   // the batch shape: units of one 1920x1080 4:2:0 frame = uploads of 4.18 + 1.04 + 1.04 MB, download of 6.27 MB.
+   // (a) all uploads on one stream  (b) one upload stream per component  (c) two frames per unit on one stream
+   {
+      const size_t Y = (size_t)240 * 136 * 128, Cc = (size_t)120 * 68 * 128, O = (size_t)1920 * 1088 * 3;
+      const int N = 8;    // frames that fit the 50 MB raster buffer (8 x 6 266 880 bytes)
+      static_assert((size_t)8 * 1920 * 1088 * 3 <= (size_t)4096 * 4096 * 3, "raster buffer too small");
+      hipEvent_t ev[3][16];
+      for (auto &r : ev) for (auto &e : r) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      hipEvent_t kd[16];
+      for (auto &e : kd) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      // the library's pipeline: + a kernel between the wait and the download, + the upload of unit k waiting for the
+      // kernel of unit k-3 (device slots)
+      auto run_lib = [&](bool kernel, bool back_edge, int reps) {
+         for (int r = 0; r < reps; r++)
+         for (int k = 0; k < N; k++) {
+            size_t o = (size_t)k * (Y + 2 * Cc);
+            const size_t sz[3] = { Y, Cc, Cc };
+            if (back_edge && (k >= 3 || r > 0)) (void)hipStreamWaitEvent(s[0], kd[(k + N - 3) % N], 0);
+            for (int c = 0; c < 3; c++) { (void)hipMemcpyAsync((char *)d_in + o, (char *)h_in + o, sz[c], hipMemcpyHostToDevice, s[0]); o += sz[c]; }
+            (void)hipEventRecord(ev[0][k], s[0]);
+            (void)hipStreamWaitEvent(s[3], ev[0][k], 0);
+            if (kernel) touch<<<256, 256, 0, s[3]>>>((unsigned *)d_out + (size_t)k * (O / 4), 1024);
+            (void)hipEventRecord(kd[k], s[3]);
+            (void)hipMemcpyAsync((char *)h_out + (size_t)k * O, (char *)d_out + (size_t)k * O, O, hipMemcpyDeviceToHost, s[3]);
+         }
+         sync_all();
+      };
+      auto run = [&](int nup, int group) {
+         for (int k = 0; k < N; k += group) {
+            const size_t in0 = (size_t)k * (Y + 2 * Cc), sz[3] = { Y * group, Cc * group, Cc * group };
+            size_t o = in0;
+            for (int c = 0; c < 3; c++) {
+               hipStream_t su = s[c % nup];
+               (void)hipMemcpyAsync((char *)d_in + o, (char *)h_in + o, sz[c], hipMemcpyHostToDevice, su);
+               o += sz[c];
+               if (c == 2 || nup > 1) { (void)hipEventRecord(ev[c][k], su); (void)hipStreamWaitEvent(s[3], ev[c][k], 0); }
+            }
+            (void)hipMemcpyAsync((char *)h_out + (size_t)k * O, (char *)d_out + (size_t)k * O, O * group, hipMemcpyDeviceToHost, s[3]);
+         }
+         sync_all();
+      };
+      const size_t bytes = (size_t)N * (Y + 2 * Cc + O);
+      report("1080p units: 3 uploads on ONE stream + download stream", median_ms(R, [&] { run(1, 1); }), bytes);
+      report("1080p units: one upload stream per component + download", median_ms(R, [&] { run(3, 1); }), bytes);
+      report("1080p units, 2 frames each: one upload stream + download", median_ms(R, [&] { run(1, 2); }), bytes);
+      report("1080p units, 4 frames each: one upload stream + download", median_ms(R, [&] { run(1, 4); }), bytes);
+      report("1080p units, 2 frames each: three upload streams + download", median_ms(R, [&] { run(3, 2); }), bytes);
+      report("8 x 1080p units x 8 rounds: as (a)", median_ms(R, [&] { run_lib(false, false, 8); }), bytes * 8);
+      report("8 x 1080p units x 8 rounds: + kernel before the download", median_ms(R, [&] { run_lib(true, false, 8); }), bytes * 8);
+      report("8 x 1080p units x 8 rounds: + upload waits for kernel k-3", median_ms(R, [&] { run_lib(false, true, 8); }), bytes * 8);
+      report("8 x 1080p units x 8 rounds: + both", median_ms(R, [&] { run_lib(true, true, 8); }), bytes * 8);
    }
    return 0;
 }
