@@ -414,8 +414,8 @@ int run_host(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, uint32_t first, 
    // Device side: every unit of the call has a slot of its own (coefficients + raster band) as long as that stays within
    // kDeviceStagingBytes; a longer call goes round the slots, and waits for everything queued each time it starts over
    // (1 GiB of traffic apart: 13 ms of transfers for one drained pipeline).  No finer-grained reuse: an upload stream that
-   // waits for an event of the download stream, or a host that waits inside the queueing loop, halves the throughput
-   // (the two directions stop overlapping; tools/probe_pcie.hip, profiles/r02_probe_pcie.txt).
+   // waits for an event of the download stream more than halves the throughput (the two directions stop overlapping;
+   // tools/probe_pcie.hip, profiles/r02_probe_pcie.txt).
    uint32_t nslots = (uint32_t)std::min<size_t>((tuning().staging_bytes ? tuning().staging_bytes : kDeviceStagingBytes) / (slot_in + slot_out), 0x7FFFFFFF);
    if (nslots < 2) nslots = 2;
    if (nslots > nunits) nslots = nunits;
