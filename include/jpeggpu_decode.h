@@ -88,7 +88,9 @@ int  jpeggpu_jpeg_next_header(jpeggpu_jpeg_t *j);
  * jpeggpu_backend_run.  Planes stay resident on the device between calls; only what the scans since
  * the previous render changed is uploaded again: the plane of a component an AC (or baseline) scan
  * touched, and for a component that only DC scans touched (src/progressive.c:98-126) just the dirty
- * spectral band -- coefficient 0 of every block, 2 of each 128 bytes -- which a small kernel puts in place. */
+ * spectral band -- coefficient 0 of every block, 2 of each 128 bytes -- which a small kernel puts in place.
+ * A raster in pinned memory (jpeggpu_host_alloc) receives the download in place; any other goes through the
+ * handle's own pinned raster and one copy.                                                                  */
 int  jpeggpu_jpeg_render(jpeggpu_jpeg_t *j, uint8_t *out, size_t out_stride);
 /* Host-to-device bytes this handle has queued so far (a measure of the hand-off, for tests and tuning). */
 size_t jpeggpu_jpeg_uploaded_bytes(const jpeggpu_jpeg_t *j);

@@ -218,7 +218,9 @@ void fill_desc(const jpegfe::Decoder &d, jpeggpu_frame_desc_t *desc) {
 }
 
 // Queue upload of the dirty planes, the fused kernel and the download of the raster.
-int render_begin(jpeggpu_jpeg *j) {
+// direct != NULL: pinned caller memory the raster is downloaded into in place (rows direct_stride bytes apart) instead of
+// into the handle's own pinned raster.
+int render_begin(jpeggpu_jpeg *j, uint8_t *direct = nullptr, size_t direct_stride = 0) {
    jpegfe::Decoder &d = j->d;
    jpeggpu_frame_desc_t desc;
    fill_desc(d, &desc);
@@ -245,9 +247,9 @@ int render_begin(jpeggpu_jpeg *j) {
       j->out_bytes = jpeggpu_raster_rows(&desc) * jpeggpu_raster_row_bytes(&desc);
       if (j->device < 0) j->device = current_device();
       if (!j->d_out) HIP_TRYD(dev_alloc(&j->d_out, j->out_bytes ? j->out_bytes : 16, j->device));
-      if (!j->h_out) HIP_TRYD(host_alloc((void **)&j->h_out, j->out_bytes ? j->out_bytes : 16, j->device));
       j->gpu = true;
    }
+   if (!direct && !j->h_out) HIP_TRYD(host_alloc((void **)&j->h_out, j->out_bytes ? j->out_bytes : 16, j->device));
    // Per-scan hand-off (src/progressive.c:209-331 runs the whole back end after every scan): a component that only DC
    // scans touched since its last upload sends the dirty spectral band -- coefficient 0, 2 of every 128 bytes -- and a
    // small kernel puts it in place; the first time round the device plane is cleared instead of uploaded (everything
@@ -271,7 +273,10 @@ int render_begin(jpeggpu_jpeg *j) {
    HIP_TRYD(hipEventRecord(j->uploaded, j->stream));
    rc = jpeggpu_backend_run_device(&desc, (const void *const *)j->d_plane, qt, j->d_out, 0, j->stream);
    if (rc) return rc;
-   HIP_TRYD(hipMemcpyAsync(j->h_out, j->d_out, j->out_bytes, hipMemcpyDeviceToHost, j->stream));
+   const size_t rb = jpeggpu_raster_row_bytes(&desc);
+   if (!direct) HIP_TRYD(hipMemcpyAsync(j->h_out, j->d_out, j->out_bytes, hipMemcpyDeviceToHost, j->stream));
+   else if (direct_stride == rb) HIP_TRYD(hipMemcpyAsync(direct, j->d_out, j->out_bytes, hipMemcpyDeviceToHost, j->stream));
+   else if (rb) HIP_TRYD(hipMemcpy2DAsync(direct, direct_stride, j->d_out, rb, rb, j->out_bytes / rb, hipMemcpyDeviceToHost, j->stream));
    j->in_flight = true;
    return 0;
 }
@@ -427,10 +432,13 @@ int jpeggpu_jpeg_render(jpeggpu_jpeg_t *j, uint8_t *out, size_t out_stride) {
    const size_t rb = jpeggpu_raster_row_bytes(&desc), rows = jpeggpu_raster_rows(&desc);
    if (out_stride == 0) out_stride = rb;
    if (out_stride < rb) { jpeggpu_internal_set_error("out_stride plus petit qu'une ligne"); return JPEGGPU_ERR_INVALID_ARG; }
-   int rc = render_begin(j);
+   hipPointerAttribute_t pa;
+   const bool direct = j->pinned && rb * rows != 0 && hipPointerGetAttributes(&pa, out) == hipSuccess && pa.type == hipMemoryTypeHost;
+   if (!direct) (void)hipGetLastError();
+   int rc = render_begin(j, direct ? out : nullptr, out_stride);
    if (rc) return rc;
    rc = render_end(j);
-   if (rc) return rc;
+   if (rc || direct) return rc;
    if (out_stride == rb) memcpy(out, j->h_out, rb * rows);
    else for (size_t r = 0; r < rows; r++) memcpy(out + r * out_stride, j->h_out + r * rb, rb);
    return 0;

@@ -131,12 +131,16 @@ class Jpeg:
         """Host-to-device bytes queued by the renders of this file so far."""
         return lib.jpeggpu_jpeg_uploaded_bytes(self._h)
 
-    def render(self):
-        """GPU back end over the current planes -> (rows, row_bytes) uint8 raster."""
+    def render(self, out=None):
+        """GPU back end over the current planes -> (rows, row_bytes) uint8 raster.  out: a C-contiguous uint8 array of at
+        least (rows, row_bytes) to fill instead (its row pitch is used; a PinnedArray receives the download in place)."""
         d = self.desc
-        out = np.zeros((max(B.raster_rows(d), 1), max(B.raster_row_bytes(d), 1)), dtype=np.uint8)
-        B._check(lib.jpeggpu_jpeg_render(self._h, out.ctypes.data, 0))
-        return out[:B.raster_rows(d), :B.raster_row_bytes(d)]
+        rows, rb = B.raster_rows(d), B.raster_row_bytes(d)
+        if out is None:
+            out = np.zeros((max(rows, 1), max(rb, 1)), dtype=np.uint8)
+        assert out.dtype == np.uint8 and out.ndim == 2 and out.shape[0] >= rows and out.shape[1] >= rb and out.strides[1] == 1
+        B._check(lib.jpeggpu_jpeg_render(self._h, out.ctypes.data, out.strides[0]))
+        return out[:rows, :rb]
 
 
 def pnm_header(desc):

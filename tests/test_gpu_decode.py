@@ -256,3 +256,35 @@ def test_closed_files_hand_their_buffers_to_the_next_one(gpu):
         assert [hashlib.sha256(img).hexdigest()] == expected_images(EXPECT[name])
         j.close()
     assert addr[0] != 0 and addr[1] == addr[0] and addr[2] == addr[0]
+
+
+def test_render_into_pinned_memory_in_place(gpu):
+    """jpeggpu_jpeg_render with a raster from jpeggpu_host_alloc: the download lands there directly (packed and padded
+    rows), scan by scan for a progressive file, interleaved with ordinary renders; every image equals the reference's."""
+    from jpeg_decoder_amd import frontend as F
+    for name in ("c4_prog422_160x120.jpg", "c1_gray_512x512_q90.jpg", "base_420_61x47_q80.jpg"):
+        j = F.Jpeg(open(os.path.join(JDIR, name), "rb").read())
+        d = j.desc
+        rows, rb = gpu.raster_rows(d), gpu.raster_row_bytes(d)
+        held = [gpu.PinnedArray((rows, rb), np.uint8), gpu.PinnedArray((rows + 1, rb + 13), np.uint8)]
+        try:
+            imgs, k = [], 0
+            while not j.eoi:
+                j.decode_scan()
+                if k % 3 == 2:
+                    img = j.render()
+                else:
+                    dst = held[k % 3].array
+                    dst[...] = 0xCD
+                    img = j.render(out=dst)
+                    if k % 3 == 1:
+                        assert np.all(dst[:, rb:] == 0xCD) and np.all(dst[rows:] == 0xCD)
+                imgs.append(F.pnm_header(d) + np.ascontiguousarray(img).tobytes())
+                k += 1
+                if j.eoi:
+                    break
+                j.next_header()
+            assert [hashlib.sha256(b).hexdigest() for b in imgs] == expected_images(EXPECT[name]), name
+        finally:
+            j.close()
+            [h.free() for h in held]
