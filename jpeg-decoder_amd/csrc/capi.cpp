@@ -556,6 +556,7 @@ int jpeggpu_internal_ensure_init(void) { jpeggpu_ctx_s *c; return default_ctx(&c
 int jpeggpu_internal_device(void) { jpeggpu_ctx_s *c = g_default.load(); return c ? c->device : 0; }
 // tests and tools change the knobs inside one process: they ask for the environment to be read again
 void jpeggpu_internal_reload_tuning(void) { (void)tuning(); read_tuning(); }
+size_t jpeggpu_internal_stripe_bytes(void) { return tuning().stripe_bytes; }   // decode_api.cpp: rows handed on per step of a streamed baseline file
 
 int jpeggpu_init(int device) {
    std::lock_guard<std::mutex> lk(g_mu);

@@ -15,9 +15,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <string>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 #include "../../include/jpeggpu_decode.h"
@@ -41,6 +46,7 @@ int dfail(int code, const char *fmt, ...) {
 // capi.cpp: lets this file report through jpeggpu_last_error()
 extern "C" void jpeggpu_internal_set_error(const char *msg);
 extern "C" int jpeggpu_internal_ensure_init(void);
+extern "C" size_t jpeggpu_internal_stripe_bytes(void);
 
 struct jpeggpu_jpeg {
    jpegfe::Decoder d;
@@ -57,6 +63,7 @@ struct jpeggpu_jpeg {
    size_t uploaded_bytes = 0;                         // host-to-device bytes queued so far (jpeggpu_jpeg_uploaded_bytes)
    void *d_out = nullptr;
    uint8_t *h_out = nullptr;      // pinned raster
+   uint8_t *h_alt[3] = { nullptr, nullptr, nullptr };   // further pinned rasters (jpeggpu_jpeg2ppm: images are written to their files while later ones are decoded and rendered)
    size_t out_bytes = 0;
    bool in_flight = false;        // a render has been queued and not yet waited for
 };
@@ -191,6 +198,7 @@ void free_all(jpeggpu_jpeg *j) {
    for (int c = 0; c < 3; c++) pool_give(true, j->d.dc_pack[c], j->plane_bytes[c] / 64, dev);
    pool_give(false, j->d_out, j->out_bytes ? j->out_bytes : 16, dev);
    pool_give(true, j->h_out, j->out_bytes ? j->out_bytes : 16, dev);
+   for (uint8_t *p : j->h_alt) pool_give(true, p, j->out_bytes ? j->out_bytes : 16, dev);
    if (j->uploaded) (void)hipEventDestroy(j->uploaded);
    if (j->stream) (void)hipStreamDestroy(j->stream);
    for (int c = 0; c < 3; c++)
@@ -217,22 +225,9 @@ void fill_desc(const jpegfe::Decoder &d, jpeggpu_frame_desc_t *desc) {
    }
 }
 
-// Queue upload of the dirty planes, the fused kernel and the download of the raster.
-// direct != NULL: pinned caller memory the raster is downloaded into in place (rows direct_stride bytes apart) instead of
-// into the handle's own pinned raster.
-int render_begin(jpeggpu_jpeg *j, uint8_t *direct = nullptr, size_t direct_stride = 0) {
+// The device side of a handle: stream, event, device planes and raster (and the pinned raster unless the caller brings one).
+int prepare_gpu(jpeggpu_jpeg *j, const jpeggpu_frame_desc_t &desc, bool own_raster) {
    jpegfe::Decoder &d = j->d;
-   jpeggpu_frame_desc_t desc;
-   fill_desc(d, &desc);
-   const jpeggpu_qtable_t *qt[4];
-   for (int i = 0; i < 4; i++) qt[i] = d.qt_present[i] ? (const jpeggpu_qtable_t *)d.qt[i] : nullptr;
-   // src/progressive.c:262-267: a component without its table is ERR_NO_HT there
-   for (int c = 0; c < d.nbcomp; c++)
-      if (d.comp[c].idq > 3 || !qt[d.comp[c].idq]) {
-         dfail(JPEGGPU_ERR_NO_HT, "Pas de table de quantification pour la composante %d", c);
-         jpeggpu_internal_set_error(g_derr);
-         return JPEGGPU_ERR_NO_HT;
-      }
    int rc = jpeggpu_internal_ensure_init();
    if (rc) return rc;
    if (!j->gpu) {   // allocate what is still missing (a retry after a failed attempt keeps what it already has)
@@ -249,7 +244,28 @@ int render_begin(jpeggpu_jpeg *j, uint8_t *direct = nullptr, size_t direct_strid
       if (!j->d_out) HIP_TRYD(dev_alloc(&j->d_out, j->out_bytes ? j->out_bytes : 16, j->device));
       j->gpu = true;
    }
-   if (!direct && !j->h_out) HIP_TRYD(host_alloc((void **)&j->h_out, j->out_bytes ? j->out_bytes : 16, j->device));
+   if (own_raster && !j->h_out) HIP_TRYD(host_alloc((void **)&j->h_out, j->out_bytes ? j->out_bytes : 16, j->device));
+   return 0;
+}
+
+// Queue upload of the dirty planes, the fused kernel and the download of the raster.
+// direct != NULL: pinned caller memory the raster is downloaded into in place (rows direct_stride bytes apart) instead of
+// into the handle's own pinned raster.
+int render_begin(jpeggpu_jpeg *j, uint8_t *direct = nullptr, size_t direct_stride = 0) {
+   jpegfe::Decoder &d = j->d;
+   jpeggpu_frame_desc_t desc;
+   fill_desc(d, &desc);
+   const jpeggpu_qtable_t *qt[4];
+   for (int i = 0; i < 4; i++) qt[i] = d.qt_present[i] ? (const jpeggpu_qtable_t *)d.qt[i] : nullptr;
+   // src/progressive.c:262-267: a component without its table is ERR_NO_HT there
+   for (int c = 0; c < d.nbcomp; c++)
+      if (d.comp[c].idq > 3 || !qt[d.comp[c].idq]) {
+         dfail(JPEGGPU_ERR_NO_HT, "Pas de table de quantification pour la composante %d", c);
+         jpeggpu_internal_set_error(g_derr);
+         return JPEGGPU_ERR_NO_HT;
+      }
+   int rc = prepare_gpu(j, desc, direct == nullptr);
+   if (rc) return rc;
    // Per-scan hand-off (src/progressive.c:209-331 runs the whole back end after every scan): a component that only DC
    // scans touched since its last upload sends the dirty spectral band -- coefficient 0, 2 of every 128 bytes -- and a
    // small kernel puts it in place; the first time round the device plane is cleared instead of uploaded (everything
@@ -293,13 +309,17 @@ int render_end(jpeggpu_jpeg *j) {
    return 0;
 }
 
+void write_pnm_header(FILE *f, const jpeggpu_frame_desc_t *desc) {   // src/baseline.c:121-130
+   fprintf(f, desc->nbcomp == 1 ? "P5\n" : "P6\n");
+   fprintf(f, "%d %d\n", desc->width, desc->height);
+   fprintf(f, "255\n");
+}
+
 int write_pnm(const char *path, const jpeggpu_frame_desc_t *desc, const uint8_t *raster, size_t stride, size_t rows) {
    FILE *f = fopen(path, "w");
    if (!f) return dfail(JPEGGPU_ERR_IO, "ouverture de '%s' impossible", path);
    const size_t rb = jpeggpu_raster_row_bytes(desc);
-   fprintf(f, desc->nbcomp == 1 ? "P5\n" : "P6\n");
-   fprintf(f, "%d %d\n", desc->width, desc->height);
-   fprintf(f, "255\n");
+   write_pnm_header(f, desc);
    bool ok = true;
    if (rows && rb) {
       if (stride == rb) ok = fwrite(raster, 1, rb * rows, f) == rb * rows;
@@ -308,6 +328,87 @@ int write_pnm(const char *path, const jpeggpu_frame_desc_t *desc, const uint8_t 
    if (fclose(f) != 0) ok = false;
    return ok ? 0 : dfail(JPEGGPU_ERR_IO, "écriture de '%s' incomplète", path);
 }
+
+// A baseline file is handed on while it is being decoded: every few MCU rows the finished rows are uploaded, converted
+// and downloaded on the handle's stream, and a thread of its own appends them to the output file as their downloads
+// complete -- so at the end of the entropy decoding only the last rows are left to do.  (What the file holds is what
+// decode_baseline_image writes, src/baseline.c:89-231: the header and every complete MCU row, also of a damaged scan.)
+struct BandWriter {
+   struct Job { hipEvent_t ready; const uint8_t *p; size_t bytes; };
+   FILE *f; int device;
+   std::thread th;
+   std::mutex mu;
+   std::condition_variable cv;
+   std::deque<Job> q;
+   uint64_t posted = 0, done = 0;
+   bool failed = false, started = false, threaded = false, stop = false;
+   BandWriter(FILE *f_, int dev) : f(f_), device(dev) {}
+   void run_one(const Job &job) {   // mu NOT held
+      bool ok = hipEventSynchronize(job.ready) == hipSuccess;
+      if (ok && job.bytes) ok = fwrite(job.p, 1, job.bytes, f) == job.bytes;
+      std::lock_guard<std::mutex> lk(mu);
+      if (!ok) failed = true;
+      done++;
+      cv.notify_all();
+   }
+   void loop() {
+      (void)hipSetDevice(device);
+      for (;;) {
+         Job job;
+         { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || !q.empty(); }); if (q.empty()) return; job = q.front(); q.pop_front(); }
+         run_one(job);
+      }
+   }
+   void post(hipEvent_t ready, const uint8_t *p, size_t bytes) {
+      if (!started) {
+         started = true;
+         try { th = std::thread([this] { loop(); }); threaded = true; } catch (const std::system_error &) { threaded = false; }
+      }
+      { std::lock_guard<std::mutex> lk(mu); posted++; if (threaded) q.push_back(Job{ ready, p, bytes }); }
+      if (threaded) cv.notify_all(); else run_one(Job{ ready, p, bytes });
+   }
+   bool drain() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done >= posted; }); return !failed; }   // everything posted is in the file
+   ~BandWriter() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if (th.joinable()) th.join(); }
+};
+
+struct BaselineStream {
+   jpeggpu_jpeg *j;
+   jpeggpu_frame_desc_t desc;
+   const jpeggpu_qtable_t *qt[4];
+   size_t band_bytes = 0, row_in[3] = { 0, 0, 0 };   // raster bytes / plane bytes of one MCU row
+   uint32_t sent = 0;                                 // MCU rows handed on so far
+   int rc = 0;                                        // first GPU error (its text is in jpeggpu_last_error())
+   std::vector<hipEvent_t> events;
+   BandWriter *writer = nullptr;
+   // MCU rows [sent, upto): upload, kernel, download, and a job for the writer
+   int send(uint32_t upto) {
+      if (rc || upto <= sent) return rc;
+      const uint32_t m0 = sent, n = upto - sent;
+      const void *dc[3] = { nullptr, nullptr, nullptr };
+      for (int c = 0; c < desc.nbcomp; c++) {
+         char *dst = (char *)j->d_plane[c] + (size_t)m0 * row_in[c];
+         hipError_t e = hipMemcpyAsync(dst, (const char *)j->d.plane[c] + (size_t)m0 * row_in[c], (size_t)n * row_in[c], hipMemcpyHostToDevice, j->stream);
+         if (e != hipSuccess) { dfail(JPEGGPU_ERR_HIP, "hipMemcpyAsync (rows %u..%u): %s", m0, upto, hipGetErrorString(e)); jpeggpu_internal_set_error(g_derr); return rc = JPEGGPU_ERR_HIP; }
+         dc[c] = dst;
+      }
+      jpeggpu_frame_desc_t sd = desc;
+      sd.nbmcuV = n;
+      uint8_t *d_band = (uint8_t *)j->d_out + (size_t)m0 * band_bytes;
+      int r = jpeggpu_backend_run_device(&sd, dc, qt, d_band, 0, j->stream);
+      if (r) return rc = r;
+      hipEvent_t ev = nullptr;
+      hipError_t e = hipMemcpyAsync(j->h_out + (size_t)m0 * band_bytes, d_band, (size_t)n * band_bytes, hipMemcpyDeviceToHost, j->stream);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+      if (e == hipSuccess) { events.push_back(ev); e = hipEventRecord(ev, j->stream); }
+      if (e != hipSuccess) { dfail(JPEGGPU_ERR_HIP, "download of rows %u..%u: %s", m0, upto, hipGetErrorString(e)); jpeggpu_internal_set_error(g_derr); return rc = JPEGGPU_ERR_HIP; }
+      j->in_flight = true;
+      writer->post(ev, j->h_out + (size_t)m0 * band_bytes, (size_t)n * band_bytes);
+      sent = upto;
+      return 0;
+   }
+   static int hook(void *ctx, uint32_t rows_done) { return static_cast<BaselineStream *>(ctx)->send(rows_done); }
+   ~BaselineStream() { for (hipEvent_t e : events) (void)hipEventDestroy(e); }
+};
 
 std::string out_name(const char *filepath, const char *outfile, uint8_t nbcomp, uint8_t nb) {
    std::string base = outfile ? outfile : filepath;
@@ -519,36 +620,115 @@ int jpeggpu_jpeg2ppm_timed(const char *filepath, const char *outfile, int *nb_im
       // decode_baseline_image, src/baseline.c:89-231: the output file exists (header + the complete MCU
       // rows) even when the scan turns out to be corrupt
       std::string name = out_name(filepath, outfile, desc.nbcomp, 0);
-      int drc;
-      { Lap lap(tm.vld_s); drc = report(j, j->d.decode_scan()); }
-      std::string derr = j->d.err;
-      size_t rows = drc ? (size_t)j->d.mcu_rows_done * desc.max_v * 8 : jpeggpu_raster_rows(&desc);
-      if (drc) for (int c = 0; c < desc.nbcomp; c++) { j->d.dirty[c] = true; j->d.dirty_kind[c] = jpegfe::Decoder::kWhole; }
-      rc = 0;
-      if (rows && rb) { Lap lap(tm.gpu_wait_s); rc = render_begin(j); if (!rc) rc = render_end(j); }
-      if (!rc) {
-         Lap lap(tm.write_s);
-         rc = write_pnm(name.c_str(), &desc, j->h_out, rb, rows);
-         if (rc) jpeggpu_internal_set_error(g_derr);
-         else written = 1;
+      const size_t total_rows = jpeggpu_raster_rows(&desc);
+      int gpu_rc = 0;
+      if (total_rows && rb) { Lap lap(tm.gpu_wait_s); gpu_rc = prepare_gpu(j, desc, true); }
+      FILE *f = nullptr;
+      int io_rc = 0;
+      if (!gpu_rc) {
+         f = fopen(name.c_str(), "w");
+         if (!f) { io_rc = dfail(JPEGGPU_ERR_IO, "ouverture de '%s' impossible", name.c_str()); }
+         else write_pnm_header(f, &desc);
       }
-      if (drc) { jpeggpu_internal_set_error(derr.c_str()); rc = drc; }
+      int drc, wr_ok = 1;
+      {
+         BandWriter writer(f, j->device);                       // declared before the stream state: joined after the last job
+         BaselineStream S;
+         S.j = j; S.desc = desc; S.writer = &writer;
+         for (int i = 0; i < 4; i++) S.qt[i] = j->d.qt_present[i] ? (const jpeggpu_qtable_t *)j->d.qt[i] : nullptr;
+         S.band_bytes = (size_t)desc.max_v * 8 * rb;
+         size_t in_per_row = 0;
+         for (int c = 0; c < desc.nbcomp; c++) { S.row_in[c] = (size_t)desc.nbmcuH * desc.comp[c].hs * desc.comp[c].vs * sizeof(jpeggpu_blocl16_t); in_per_row += S.row_in[c]; }
+         const bool streaming = f && total_rows && rb;
+         if (streaming) {
+            const size_t step = jpeggpu_internal_stripe_bytes() ? jpeggpu_internal_stripe_bytes() : ((size_t)8 << 20);
+            j->d.row_hook = &BaselineStream::hook;
+            j->d.row_hook_ctx = &S;
+            j->d.row_hook_every = (uint32_t)std::max<size_t>(1, step / (in_per_row ? in_per_row : 1));
+         }
+         { Lap lap(tm.vld_s); drc = j->d.decode_scan(); }
+         j->d.row_hook = nullptr;
+         if (drc && S.rc && drc == S.rc) drc = 0;                // the hook ended the scan: a GPU error (gpu_rc below), not a decoding error
+         else if (drc) report(j, drc);
+         std::string derr = j->d.err;
+         const uint32_t mcu_rows = (drc || S.rc) ? j->d.mcu_rows_done : desc.nbmcuV;
+         if (streaming) {
+            { Lap lap(tm.gpu_wait_s); (void)S.send(mcu_rows); }  // the rows after the last hook (all of them for a small file)
+            { Lap lap(tm.write_s); wr_ok = writer.drain(); }
+            { Lap lap(tm.gpu_wait_s); int r = render_end(j); if (!S.rc) S.rc = r; }
+            if (S.rc) gpu_rc = S.rc;
+         }
+         if (f) {
+            Lap lap(tm.write_s);
+            if (fclose(f) != 0) wr_ok = 0;
+            if (!wr_ok && !io_rc) io_rc = dfail(JPEGGPU_ERR_IO, "écriture de '%s' incomplète", name.c_str());
+            if (!io_rc && !gpu_rc) written = 1;
+         }
+         rc = gpu_rc ? gpu_rc : io_rc;
+         if (io_rc && !gpu_rc) jpeggpu_internal_set_error(g_derr);
+         if (drc) { jpeggpu_internal_set_error(derr.c_str()); rc = drc; }
+      }
    } else {
-      // decode_progressive_image, src/progressive.c:188-349: one image per scan
-      uint64_t k = 1;
+      // decode_progressive_image, src/progressive.c:188-349: one image per scan.  Writing an image (10 ms for 50 MB) is
+      // left to a thread of its own, so that it overlaps the entropy decoding of the following scans like the GPU work
+      // does (a scan of a chroma component decodes faster than its image is written: the writer may lag up to three
+      // images behind, images go round four pinned rasters).  Files are written in order, one at a time; after a failed
+      // write nothing more is written.
+      struct Writer {
+         struct Job { std::string name; const uint8_t *raster; };
+         const jpeggpu_frame_desc_t &desc; size_t rb, nrows;
+         std::thread th;
+         std::mutex mu;
+         std::condition_variable cv;
+         std::deque<Job> q;
+         uint64_t posted = 0, done = 0;
+         int written = 0, rc = 0;
+         std::string err;
+         bool started = false, threaded = false, stop = false;
+         Writer(const jpeggpu_frame_desc_t &d, size_t rb_, size_t nrows_) : desc(d), rb(rb_), nrows(nrows_) {}
+         void run_one(const Job &job) {   // mu NOT held
+            int r = 0; std::string e;
+            bool skip; { std::lock_guard<std::mutex> lk(mu); skip = rc != 0; }
+            if (!skip) { r = write_pnm(job.name.c_str(), &desc, job.raster, rb, nrows); if (r) e = g_derr; }   // g_derr is thread-local
+            std::lock_guard<std::mutex> lk(mu);
+            if (!skip) { if (r) { rc = r; err = e; } else written++; }
+            done++;
+            cv.notify_all();
+         }
+         void loop() {
+            for (;;) {
+               Job job;
+               { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || !q.empty(); }); if (q.empty()) return; job = q.front(); q.pop_front(); }
+               run_one(job);
+            }
+         }
+         void post(const std::string &name, const uint8_t *raster) {
+            if (!started) {
+               started = true;
+               try { th = std::thread([this] { loop(); }); threaded = true; } catch (const std::system_error &) { threaded = false; }
+            }
+            { std::lock_guard<std::mutex> lk(mu); posted++; if (threaded) q.push_back(Job{ name, raster }); }
+            if (threaded) cv.notify_all(); else run_one(Job{ name, raster });   // no thread to be had: write here
+         }
+         int wait_done(uint64_t n) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done >= n; }); return rc; }   // the first n files are on disk (or failed)
+         int status() { std::lock_guard<std::mutex> lk(mu); return rc; }
+         ~Writer() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if (th.joinable()) th.join(); }
+      } wr(desc, rb, jpeggpu_raster_rows(&desc));
+      uint64_t k = 1;                       // number of the image the next render produces (1-based, like the file names)
       std::string pending_name;
-      auto flush = [&]() -> int {   // wait for the queued render and write its file
+      const uint8_t *pending_raster = nullptr;
+      auto writer_failed = [&](int r) { if (r) jpeggpu_internal_set_error(wr.err.c_str()); return r; };
+      auto flush = [&]() -> int {   // wait for the queued render, then hand its raster to the writer
          if (pending_name.empty()) return 0;
          int r;
          { Lap lap(tm.gpu_wait_s); r = render_end(j); }
-         if (!r) {
-            Lap lap(tm.write_s);
-            r = write_pnm(pending_name.c_str(), &desc, j->h_out, rb, jpeggpu_raster_rows(&desc));
-            if (r) jpeggpu_internal_set_error(g_derr); else written++;
-         }
+         if (!r) r = writer_failed(wr.status());
+         if (!r) wr.post(pending_name, pending_raster);
          pending_name.clear();
          return r;
       };
+      constexpr uint64_t kRasters = 4;
+      uint64_t nrasters = 1;                // rasters in use: the handle's own + the h_alt that could be allocated
       while (!j->d.eoi_done) {
          int drc;
          { Lap lap(tm.vld_s); drc = report(j, j->d.decode_scan()); }   // overlaps the kernel + download of the previous scan
@@ -556,8 +736,22 @@ int jpeggpu_jpeg2ppm_timed(const char *filepath, const char *outfile, int *nb_im
          rc = flush();
          if (drc) { jpeggpu_internal_set_error(derr.c_str()); rc = drc; }
          if (rc) break;
-         { Lap lap(tm.gpu_wait_s); rc = render_begin(j); }
+         // image k goes to raster (k-1) % nrasters: 0 = the handle's own, i = h_alt[i-1], allocated the first time round
+         if (k - 1 == nrasters && nrasters < kRasters) {
+            const size_t ob = jpeggpu_raster_rows(&desc) * rb;
+            if (host_alloc((void **)&j->h_alt[nrasters - 1], ob ? ob : 16, j->device) == hipSuccess) nrasters++;
+            else { (void)hipGetLastError(); j->h_alt[nrasters - 1] = nullptr; }
+         }
+         const uint64_t slot = (k - 1) % nrasters;
+         uint8_t *const alt = slot ? j->h_alt[slot - 1] : nullptr;
+         if (k > nrasters) {                // the file written from this raster (image k - nrasters) is complete
+            Lap lap(tm.write_s);
+            rc = writer_failed(wr.wait_done(k - nrasters));
+            if (rc) break;
+         }
+         { Lap lap(tm.gpu_wait_s); rc = render_begin(j, alt, rb); }
          if (rc) break;
+         pending_raster = alt ? alt : j->h_out;
          pending_name = out_name(filepath, outfile, desc.nbcomp, (uint8_t)k);   // uint8_t parameter, src/utils.c:56
          { Lap lap(tm.gpu_wait_s); rc = render_planes_free(j); }
          if (rc) break;
@@ -567,6 +761,8 @@ int jpeggpu_jpeg2ppm_timed(const char *filepath, const char *outfile, int *nb_im
          k++;
       }
       if (!rc) rc = flush();
+      { Lap lap(tm.write_s); int w = wr.wait_done(wr.posted); if (!rc) rc = writer_failed(w); }   // every file handed over is on disk (or failed)
+      written = wr.written;
       if (!rc && k > 1) {
          // src/progressive.c:332-343: "ln -f -s <last image> <name>"
          std::string base = out_name(filepath, outfile, desc.nbcomp, 0), last = out_name(filepath, outfile, desc.nbcomp, (uint8_t)(k - 1));

@@ -1034,6 +1034,10 @@ int Decoder::scan_baseline(BitReader &br) {
          }
       }
       mcu_rows_done = my + 1;
+      if (row_hook && row_hook_every && mcu_rows_done % row_hook_every == 0 && mcu_rows_done != nbmcuV) {
+         const int hr = row_hook(row_hook_ctx, mcu_rows_done);
+         if (hr) return hr;
+      }
    }
    for (int k = 0; k < nsc; k++) { dirty[scan_c[k]] = true; dirty_kind[scan_c[k]] = kWhole; }
    return 0;

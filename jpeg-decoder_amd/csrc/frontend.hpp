@@ -77,6 +77,11 @@ struct Decoder {
    unsigned scans_decoded = 0;
    bool dequant_on_store = false;     // baseline only: store coef * qtable (int16 wrap) like decode_bloc_baseline's iquant (src/baseline.c:66)
    uint32_t mcu_rows_done = 0;        // complete MCU rows of the last baseline scan (partial output on error)
+   // baseline scans: called with the number of complete MCU rows every <row_hook_every> rows (not after the last one), so
+   // that the caller can hand finished rows on while the rest is being decoded; a non-zero return ends the scan with it
+   int (*row_hook)(void *ctx, uint32_t mcu_rows_done) = nullptr;
+   void *row_hook_ctx = nullptr;
+   uint32_t row_hook_every = 0;
    std::vector<uint8_t> scanbuf;
    std::string err;
 

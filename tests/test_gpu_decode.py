@@ -288,3 +288,37 @@ def test_render_into_pinned_memory_in_place(gpu):
         finally:
             j.close()
             [h.free() for h in held]
+
+
+@pytest.mark.parametrize("step", [1, 3000, 40000], ids=["every_mcu_row", "3kB_steps", "40kB_steps"])
+def test_jpeg2ppm_streams_baseline_files_in_small_steps(gpu, tmp_path, step):
+    """jpeggpu_jpeg2ppm hands a baseline file's finished MCU rows to the GPU and to the output file while the rest is still
+    being decoded (decode_api.cpp BaselineStream).  With steps of one MCU row / a few rows every baseline fixture -- well-formed,
+    damaged in the middle of the scan, truncated -- gives the reference's status and files, byte for byte."""
+    from jpeg_decoder_amd import frontend as F
+    old = os.environ.get("JPEGGPU_STRIPE_BYTES")
+    os.environ["JPEGGPU_STRIPE_BYTES"] = str(step)
+    gpu.reload_tuning()
+    try:
+        n = 0
+        for name in sorted(EXPECT):
+            e = EXPECT[name]
+            if name.startswith(("prog_", "c4_prog", "flip_prog", "flipmid_prog", "bad_prog")):
+                continue
+            out = tmp_path / name.replace(".", "_")
+            out.mkdir()
+            rc = 0
+            try:
+                F.jpeg2ppm(os.path.join(JDIR, name), out / "x.pnm")
+            except gpu.JpegGpuError as err:
+                rc = err.code
+            assert rc == e["rc"], (name, rc, e["err"], gpu.last_error())
+            _check_outputs(out, e)
+            n += 1
+        assert n > 60
+    finally:
+        if old is None:
+            os.environ.pop("JPEGGPU_STRIPE_BYTES", None)
+        else:
+            os.environ["JPEGGPU_STRIPE_BYTES"] = old
+        gpu.reload_tuning()
