@@ -342,6 +342,7 @@ struct BandWriter {
    std::deque<Job> q;
    uint64_t posted = 0, done = 0;
    bool failed = false, started = false, threaded = false, stop = false;
+   bool want_thread = true;               // false: a file that is handed on in one piece is written by the caller's thread
    BandWriter(FILE *f_, int dev) : f(f_), device(dev) {}
    void run_one(const Job &job) {   // mu NOT held
       bool ok = hipEventSynchronize(job.ready) == hipSuccess;
@@ -362,7 +363,7 @@ struct BandWriter {
    void post(hipEvent_t ready, const uint8_t *p, size_t bytes) {
       if (!started) {
          started = true;
-         try { th = std::thread([this] { loop(); }); threaded = true; } catch (const std::system_error &) { threaded = false; }
+         if (want_thread) { try { th = std::thread([this] { loop(); }); threaded = true; } catch (const std::system_error &) { threaded = false; } }
       }
       { std::lock_guard<std::mutex> lk(mu); posted++; if (threaded) q.push_back(Job{ ready, p, bytes }); }
       if (threaded) cv.notify_all(); else run_one(Job{ ready, p, bytes });
@@ -645,6 +646,7 @@ int jpeggpu_jpeg2ppm_timed(const char *filepath, const char *outfile, int *nb_im
             j->d.row_hook = &BaselineStream::hook;
             j->d.row_hook_ctx = &S;
             j->d.row_hook_every = (uint32_t)std::max<size_t>(1, step / (in_per_row ? in_per_row : 1));
+            writer.want_thread = j->d.row_hook_every < desc.nbmcuV;
          }
          { Lap lap(tm.vld_s); drc = j->d.decode_scan(); }
          j->d.row_hook = nullptr;
