@@ -115,14 +115,16 @@ int  jpeggpu_jpeg2ppm(const char *filepath, const char *outfile, int *nb_images)
 /* The stages the reference times under -t (print_timer, src/timer.c:36-45; call sites src/jpeg2ppm.c:84-94,
  * :134-135, src/baseline.c:224-228, src/progressive.c:316-321), for this library's decomposition of the work.
  * Host wall-clock seconds.  gpu_wait_s is the time the host thread spent enqueuing uploads/launches and
- * waiting for rasters; for progressive files most GPU work hides behind the entropy decoding of the next
- * scan, so the parts do not add up to the GPU's busy time.                                          */
+ * waiting for rasters, write_s the time it waited for the thread that writes the files: GPU work and file
+ * writing overlap the entropy decoding (of the next scans of a progressive file, of the following MCU rows of
+ * a baseline file), so the parts do not add up to the GPU's or the writer's busy time.                  */
 typedef struct jpeggpu_timing_s {
    double init_s;      /* binding the GPU (HIP runtime start-up, stream): first call of the process only        */
    double header_s;    /* "Décodage entête" + the headers between scans                                   */
-   double vld_s;       /* "Décodage DC/AC et Quantification" (entropy decoding only; iquant runs on the GPU) */
+   double vld_s;       /* "Décodage DC/AC et Quantification" (entropy decoding; iquant runs on the GPU; a baseline
+                          file's hand-over of finished rows, some tens of microseconds each, is inside)         */
    double gpu_wait_s;  /* upload + kernel + download as seen by the host thread (IZZ + IDCT + colour)      */
-   double write_s;     /* "Ecriture de l'image"                                                           */
+   double write_s;     /* "Ecriture de l'image": what of it the host thread had to wait for                 */
    double total_s;     /* "Temps total"                                                                   */
 } jpeggpu_timing_t;
 /* jpeggpu_jpeg2ppm with the stage times; timing may be NULL.                                             */
