@@ -674,16 +674,17 @@ int jpeggpu_jpeg2ppm_timed(const char *filepath, const char *outfile, int *nb_im
       // decode_progressive_image, src/progressive.c:188-349: one image per scan.  Writing an image (10 ms for 50 MB) is
       // left to a thread of its own, so that it overlaps the entropy decoding of the following scans like the GPU work
       // does (a scan of a chroma component decodes faster than its image is written: the writer may lag up to three
-      // images behind, images go round four pinned rasters).  Files are written in order, one at a time; after a failed
-      // write nothing more is written.
+      // images behind, images go round four pinned rasters).  Two files are written at a time; after a failed write no
+      // further file is started.
       struct Writer {
-         struct Job { std::string name; const uint8_t *raster; };
+         struct Job { std::string name; const uint8_t *raster; uint64_t id; };
          const jpeggpu_frame_desc_t &desc; size_t rb, nrows;
-         std::thread th;
+         std::thread th[2];                 // two files at a time: a 50 MB image takes 10 ms to write, a chroma scan 3 ms to decode
          std::mutex mu;
          std::condition_variable cv;
          std::deque<Job> q;
-         uint64_t posted = 0, done = 0;
+         std::vector<char> finished;        // per job
+         uint64_t posted = 0, done = 0;     // done: jobs 0 .. done-1 are all finished
          int written = 0, rc = 0;
          std::string err;
          bool started = false, threaded = false, stop = false;
@@ -693,8 +694,9 @@ int jpeggpu_jpeg2ppm_timed(const char *filepath, const char *outfile, int *nb_im
             bool skip; { std::lock_guard<std::mutex> lk(mu); skip = rc != 0; }
             if (!skip) { r = write_pnm(job.name.c_str(), &desc, job.raster, rb, nrows); if (r) e = g_derr; }   // g_derr is thread-local
             std::lock_guard<std::mutex> lk(mu);
-            if (!skip) { if (r) { rc = r; err = e; } else written++; }
-            done++;
+            if (!skip) { if (r) { if (!rc) { rc = r; err = e; } } else written++; }
+            finished[job.id] = 1;
+            while (done < finished.size() && finished[done]) done++;
             cv.notify_all();
          }
          void loop() {
@@ -707,14 +709,16 @@ int jpeggpu_jpeg2ppm_timed(const char *filepath, const char *outfile, int *nb_im
          void post(const std::string &name, const uint8_t *raster) {
             if (!started) {
                started = true;
-               try { th = std::thread([this] { loop(); }); threaded = true; } catch (const std::system_error &) { threaded = false; }
+               try { th[0] = std::thread([this] { loop(); }); threaded = true; } catch (const std::system_error &) { threaded = false; }
+               if (threaded) { try { th[1] = std::thread([this] { loop(); }); } catch (const std::system_error &) {} }
             }
-            { std::lock_guard<std::mutex> lk(mu); posted++; if (threaded) q.push_back(Job{ name, raster }); }
-            if (threaded) cv.notify_all(); else run_one(Job{ name, raster });   // no thread to be had: write here
+            Job job{ name, raster, 0 };
+            { std::lock_guard<std::mutex> lk(mu); job.id = posted++; finished.push_back(0); if (threaded) q.push_back(job); }
+            if (threaded) cv.notify_all(); else run_one(job);   // no thread to be had: write here
          }
          int wait_done(uint64_t n) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done >= n; }); return rc; }   // the first n files are on disk (or failed)
          int status() { std::lock_guard<std::mutex> lk(mu); return rc; }
-         ~Writer() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if (th.joinable()) th.join(); }
+         ~Writer() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto &t : th) if (t.joinable()) t.join(); }
       } wr(desc, rb, jpeggpu_raster_rows(&desc));
       uint64_t k = 1;                       // number of the image the next render produces (1-based, like the file names)
       std::string pending_name;
