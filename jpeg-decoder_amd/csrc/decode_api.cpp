@@ -60,6 +60,7 @@ struct jpeggpu_jpeg {
    void *d_plane[3] = { nullptr, nullptr, nullptr };
    void *d_pack[3] = { nullptr, nullptr, nullptr };   // device side of Decoder::dc_pack (progressive files)
    bool d_zeroed[3] = { false, false, false };        // the device plane has been initialised (uploaded or cleared)
+   bool pack_on_device[3] = { false, false, false };  // d_pack[c] holds what dc_pack[c] held at the last render that uploaded it
    size_t uploaded_bytes = 0;                         // host-to-device bytes queued so far (jpeggpu_jpeg_uploaded_bytes)
    void *d_out = nullptr;
    uint8_t *h_out = nullptr;      // pinned raster
@@ -185,6 +186,9 @@ int alloc_planes(jpeggpu_jpeg *j) {
          else (void)hipGetLastError();   // no packed side: whole planes are uploaded
       }
    }
+   // DC scans then write coefficient 0 into the packed arrays only (2 bytes per block instead of a 128-byte line of the
+   // plane per block: the scans are memory-bound otherwise); render_begin puts the values in place on the device
+   d.dc_in_pack = j->pinned && d.num_sof == 2;
    return 0;
 }
 
@@ -273,17 +277,29 @@ int render_begin(jpeggpu_jpeg *j, uint8_t *direct = nullptr, size_t direct_strid
    for (int c = 0; c < d.nbcomp; c++)
       if (d.dirty[c] && j->plane_bytes[c]) {
          const size_t nblocks = j->plane_bytes[c] / 128;
-         if (d.dirty_kind[c] == jpegfe::Decoder::kDcOnly && j->d_pack[c] && d.dc_pack[c]) {
+         const bool have_pack = j->d_pack[c] && d.dc_pack[c];
+         if (d.dirty_kind[c] == jpegfe::Decoder::kDcOnly && have_pack) {
             if (!j->d_zeroed[c]) HIP_TRYD(hipMemsetAsync(j->d_plane[c], 0, j->plane_bytes[c], j->stream));
             HIP_TRYD(hipMemcpyAsync(j->d_pack[c], d.dc_pack[c], nblocks * 2, hipMemcpyHostToDevice, j->stream));
             HIP_TRYD(jpeggpu_k::launch_scatter_dc(j->d_plane[c], j->d_pack[c], nblocks, j->stream));
             j->uploaded_bytes += nblocks * 2;
+            j->pack_on_device[c] = true;
          } else {
             HIP_TRYD(hipMemcpyAsync(j->d_plane[c], d.plane[c], j->plane_bytes[c], hipMemcpyHostToDevice, j->stream));
             j->uploaded_bytes += j->plane_bytes[c];
+            if (d.dc_in_pack && have_pack) {
+               // the host plane carries no coefficient 0 (Decoder::dc_in_pack): put the packed values in place behind the upload
+               if (d.dc_dirty[c] || !j->pack_on_device[c]) {
+                  HIP_TRYD(hipMemcpyAsync(j->d_pack[c], d.dc_pack[c], nblocks * 2, hipMemcpyHostToDevice, j->stream));
+                  j->uploaded_bytes += nblocks * 2;
+                  j->pack_on_device[c] = true;
+               }
+               HIP_TRYD(jpeggpu_k::launch_scatter_dc(j->d_plane[c], j->d_pack[c], nblocks, j->stream));
+            }
          }
          j->d_zeroed[c] = true;
          d.dirty[c] = false;
+         d.dc_dirty[c] = false;
          d.dirty_kind[c] = jpegfe::Decoder::kClean;
       }
    HIP_TRYD(hipEventRecord(j->uploaded, j->stream));
@@ -507,6 +523,7 @@ const jpeggpu_qtable_t *jpeggpu_jpeg_qtable(const jpeggpu_jpeg_t *j, int idq) {
 
 const jpeggpu_blocl16_t *jpeggpu_jpeg_plane(const jpeggpu_jpeg_t *j, int c) {
    if (!j || c < 0 || c >= j->d.nbcomp || c > 2) return nullptr;
+   const_cast<jpeggpu_jpeg_t *>(j)->d.merge_dc_into_planes(c);   // progressive files on a GPU keep coefficient 0 packed while decoding
    return (const jpeggpu_blocl16_t *)j->d.plane[c];
 }
 

@@ -1064,35 +1064,48 @@ int Decoder::scan_progressive_dc(BitReader &br) {
                for (unsigned bx = 0; bx < ci.hs; bx++) {
                   if (ci.idhdc > 3 || !hdc[ci.idhdc].present)   // src/progressive.c:53-57
                      return fail(JPEGGPU_ERR_NO_HT, "Pas de table de huffman DC pour la composante %d", c);
-                  int16_t *blk = plane[c] + (((size_t)my * ci.vs + by) * nbH + (size_t)mx * ci.hs + bx) * 64;
+                  const size_t bi = ((size_t)my * ci.vs + by) * nbH + (size_t)mx * ci.hs + bx;
+                  const bool packed_only = dc_in_pack && dc_pack[c];
+                  int16_t *const dc = packed_only ? dc_pack[c] + bi : plane[c] + bi * 64;   // where this block's coefficient 0 lives
                   if (ah != 0) {
                      if (ah - al != 1) return fail(JPEGGPU_ERR_DIFF_AH_AL, "La différence entre ah et al devrait être 1");
                      CheckedBits cb(br);
                      uint32_t b;
                      if (!cb.bit(b)) return fail(JPEGGPU_ERR_0XFF00, "%s", kMsgFF);
-                     blk[0] = (int16_t)(blk[0] | (int16_t)(b << al));   // src/vld.c:115-122
+                     *dc = (int16_t)(*dc | (int16_t)(b << al));   // src/vld.c:115-122
                   } else {
                      int rc;
                      if (far_from_end(br)) {
                         FastBits fb(br);
-                        rc = dc_first(fb, hdc[ci.idhdc], al, blk, err);
+                        rc = dc_first(fb, hdc[ci.idhdc], al, dc, err);
                         fb.done();
                      } else {
                         CheckedBits cb(br);
-                        rc = dc_first(cb, hdc[ci.idhdc], al, blk, err);
+                        rc = dc_first(cb, hdc[ci.idhdc], al, dc, err);
                      }
                      if (rc) return rc;
-                     blk[0] = (int16_t)(blk[0] + pred[c]);
+                     *dc = (int16_t)(*dc + pred[c]);
                   }
-                  pred[c] = blk[0];
-                  if (dc_pack[c]) dc_pack[c][((size_t)my * ci.vs + by) * nbH + (size_t)mx * ci.hs + bx] = blk[0];
+                  pred[c] = *dc;
+                  if (dc_pack[c] && !packed_only) dc_pack[c][bi] = *dc;
                }
          }
    for (int k = 0; k < nsc; k++) {
       dirty[scan_c[k]] = true;
+      dc_dirty[scan_c[k]] = true;
       if (dirty_kind[scan_c[k]] < kDcOnly) dirty_kind[scan_c[k]] = kDcOnly;
    }
    return 0;
+}
+
+// Coefficient 0 of every block from the packed arrays into the planes (dc_in_pack): for callers that read the planes.
+void Decoder::merge_dc_into_planes(int only) {
+   if (!dc_in_pack) return;
+   for (int c = 0; c < nbcomp && c < 3; c++) {
+      if ((only >= 0 && c != only) || !dc_pack[c] || !plane[c]) continue;
+      const size_t nb = plane_blocks(c);
+      for (size_t b = 0; b < nb; b++) plane[c][b * 64] = dc_pack[c][b];
+   }
 }
 
 // decode_progressif_ac (src/progressive.c:128-173): the first component of the scan only, blocks in

@@ -74,6 +74,13 @@ struct Decoder {
    enum : uint8_t { kClean = 0, kDcOnly = 1, kWhole = 2 };
    uint8_t dirty_kind[3] = { kClean, kClean, kClean };
    int16_t *dc_pack[3] = { nullptr, nullptr, nullptr };
+   // dc_in_pack: DC scans keep coefficient 0 of a component with a dc_pack ONLY there (2 bytes per block, dense) instead of
+   // touching one 128-byte line per block of the plane for it; plane[c][64 * b] then stays 0 until merge_dc_into_planes().
+   // The GPU side puts the packed values in place on the device.  dc_dirty[c]: a DC scan changed dc_pack[c] since the caller
+   // last cleared the flag.
+   bool dc_in_pack = false;
+   bool dc_dirty[3] = { false, false, false };
+   void merge_dc_into_planes(int only = -1);   // only: one component, -1 = all
    unsigned scans_decoded = 0;
    bool dequant_on_store = false;     // baseline only: store coef * qtable (int16 wrap) like decode_bloc_baseline's iquant (src/baseline.c:66)
    uint32_t mcu_rows_done = 0;        // complete MCU rows of the last baseline scan (partial output on error)
