@@ -59,24 +59,20 @@ def host_cores():
     return mine, os.cpu_count() or mine
 
 
-def reference_stage_times(name, w, h, samp):
-    """jpeg2ppm_fast -t (the reference's own -Ofast binary and its own timers, src/baseline.c:224-228) on a real JPEG
-    of the workload's geometry encoded on the spot.  None when the binary (oracle/_ref, built where /root/reference
-    exists) or Pillow is missing."""
-    exe = os.path.join(ROOT, "oracle", "_ref", "jpeg2ppm_fast")
-    if not os.path.exists(exe) or len(samp) not in (1, 3):
-        return None
+def bench_jpeg(w, h, samp):
+    """A real baseline JPEG of the workload's geometry (q90, at most ~8 MPix so that the reference stays within seconds),
+    encoded on the spot with Pillow -> (bytes, height) or (None, 0)."""
     try:
         import io
-        import tempfile
         import numpy as np
         from PIL import Image
     except ImportError:
-        return None
+        return None, 0
+    if len(samp) not in (1, 3):
+        return None, 0
     sub = {((1, 1),) * 3: 0, ((2, 1), (1, 1), (1, 1)): 1, ((2, 2), (1, 1), (1, 1)): 2}.get(tuple(samp))
     if len(samp) == 3 and sub is None:
-        return None
-    # a bounded picture: at most ~8 MPix so that the run stays within a few seconds
+        return None, 0
     hh = min(h, max(16, (8 << 20) // w // 16 * 16))
     y, x = np.mgrid[0:hh, 0:w]
     a = np.stack([(x + y) % 256, (x * 3 + y // 2) % 256, (x // 3 + y * 2) % 256], -1).astype(np.float64)
@@ -87,9 +83,46 @@ def reference_stage_times(name, w, h, samp):
         im = im.convert("L")
     else:
         kw["subsampling"] = sub
+    b = io.BytesIO()
+    im.save(b, "JPEG", **kw)
+    return b.getvalue(), hh
+
+
+def whole_file_times(w, h, samp):
+    """jpeggpu_jpeg2ppm_timed (host entropy decoding + GPU back end + file writing, overlapped) on the same JPEG that
+    cpu_baseline.jpeg2ppm_fast_t hands to the reference binary; second run (buffers of the first one reused)."""
+    import tempfile
+    from jpeg_decoder_amd import frontend as F
+    data, hh = bench_jpeg(w, h, samp)
+    if data is None:
+        return None
     with tempfile.TemporaryDirectory() as tmp:
         src = os.path.join(tmp, "in.jpg")
-        im.save(src, "JPEG", **kw)
+        with open(src, "wb") as f:
+            f.write(data)
+        t = None
+        for _ in range(2):
+            _, t = F.jpeg2ppm_timed(src, os.path.join(tmp, "o", "out.pnm"))
+        return {"entry": "jpeggpu_jpeg2ppm_timed", "picture": f"{w}x{hh} q90 JPEG ({len(data)} bytes), the one of cpu_baseline.jpeg2ppm_fast_t",
+                "header_s": round(t.header_s, 6), "vld_s": round(t.vld_s, 6), "gpu_wait_s": round(t.gpu_wait_s, 6),
+                "write_wait_s": round(t.write_s, 6), "total_s": round(t.total_s, 6), "MPix_s": round(w * hh / t.total_s / 1e6, 1)}
+
+
+def reference_stage_times(name, w, h, samp):
+    """jpeg2ppm_fast -t (the reference's own -Ofast binary and its own timers, src/baseline.c:224-228) on a real JPEG
+    of the workload's geometry encoded on the spot.  None when the binary (oracle/_ref, built where /root/reference
+    exists) or Pillow is missing."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "jpeg2ppm_fast")
+    if not os.path.exists(exe):
+        return None
+    import tempfile
+    data, hh = bench_jpeg(w, h, samp)
+    if data is None:
+        return None
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, "in.jpg")
+        with open(src, "wb") as f:
+            f.write(data)
         try:
             r = subprocess.run([exe, "-t", "-o", os.path.join(tmp, "out.pnm"), src], capture_output=True, timeout=120)
         except (subprocess.TimeoutExpired, OSError):
@@ -428,6 +461,7 @@ def main():
         if solo and not args.no_end_to_end:
             try:
                 res["end_to_end"] = end_to_end(jg, np, jg.make_desc(w, h, samp), qt, w, h)
+                res["end_to_end"]["whole_file"] = whole_file_times(w, h, samp)
             except Exception as e:      # reported, never fatal for the headline
                 res["end_to_end"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
