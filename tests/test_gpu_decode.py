@@ -322,3 +322,35 @@ def test_jpeg2ppm_streams_baseline_files_in_small_steps(gpu, tmp_path, step):
         else:
             os.environ["JPEGGPU_STRIPE_BYTES"] = old
         gpu.reload_tuning()
+
+
+def test_jpeg2ppm_from_several_threads(gpu, tmp_path):
+    """jpeggpu_jpeg2ppm called by four threads at once (every call has its own handle, stream and writer threads; buffers
+    come from and go back to the shared cache): each call's status and files are the reference's."""
+    import threading
+    from jpeg_decoder_amd import frontend as F
+    names = ["c4_prog422_160x120.jpg", "c1_gray_512x512_q90.jpg", "prog_420_128x96_q60.jpg", "ref_shaun_the_sheep.jpeg",
+             "bad_truncated_scan.jpg", "flipmid_prog_00.jpg"]
+    errors = []
+
+    def worker(t):
+        try:
+            for rep in range(3):
+                for i, name in enumerate(names[t % 3:] + names[:t % 3]):
+                    e = EXPECT[name]
+                    out = tmp_path / f"t{t}_{rep}_{i}"
+                    out.mkdir()
+                    rc = 0
+                    try:
+                        F.jpeg2ppm(os.path.join(JDIR, name), out / "x.pnm")
+                    except gpu.JpegGpuError as err:
+                        rc = err.code
+                    assert rc == e["rc"], (name, rc, e["err"])
+                    _check_outputs(out, e)
+        except BaseException as e:   # noqa: BLE001  (reported by the main thread)
+            errors.append((t, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
