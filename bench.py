@@ -455,6 +455,26 @@ def main():
         res["dry_run"] = True
     if os.environ.get("JPEGGPU_BENCH_TRACE") and rank == 0:
         print("launch_us:", " ".join(f"{x * 1e3:.0f}" for x in kernel_ms), file=sys.stderr)
+    if rank == 0 and not args.dry_run:
+        # how fast THIS box streams: a plain 1 GiB device-to-device copy (torch's copy kernel), read + write bytes per second.
+        # Boxes differ by +-3.5 %; the guide's figure for a float4 copy is 6.29 TB/s = 79 % of the peak.
+        try:
+            a = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+            b = torch.empty_like(a)
+            for _ in range(3):
+                b.copy_(a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                b.copy_(a)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbps = 10 * 2 * a.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            res["roofline"]["box_torch_copy_GBps"] = round(copy_gbps, 1)
+            res["roofline"]["achieved_vs_box_torch_copy"] = round(achieved / copy_gbps, 4)
+            del a, b
+        except Exception as e:   # noqa: BLE001  (a calibration figure only)
+            res["roofline"]["box_torch_copy_GBps"] = None
     if rank == 0:
         solo = world == 1 and not args.dry_run
         res["cpu_baseline"] = cpu_baseline(args.workload, w, h, samp, qt) if solo and not args.no_cpu_baseline else None
