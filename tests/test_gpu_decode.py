@@ -354,3 +354,27 @@ def test_jpeg2ppm_from_several_threads(gpu, tmp_path):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errors, errors
+
+
+@pytest.mark.parametrize("name", ["c1_gray_512x512_q90.jpg", "c4_prog422_160x120.jpg"])
+def test_jpeg2ppm_reports_a_file_that_cannot_be_written(gpu, tmp_path, name):
+    """The writer threads of jpeggpu_jpeg2ppm (a band writer for baseline files, image writers for progressive ones) report
+    a file that cannot be created as JPEGGPU_ERR_IO through the call's status -- no hang, no image counted -- and the
+    library goes on working afterwards."""
+    from jpeg_decoder_amd import frontend as F
+    ro = tmp_path / "ro"
+    ro.mkdir()
+    os.chmod(ro, 0o555)
+    try:
+        if os.access(ro, os.W_OK):
+            pytest.skip("running with privileges that ignore directory permissions")
+        with pytest.raises(gpu.JpegGpuError) as e:
+            F.jpeg2ppm(os.path.join(JDIR, name), ro / "x.pnm")
+        assert e.value.code == F.ERR_IO, gpu.last_error()
+        assert os.listdir(ro) == []
+    finally:
+        os.chmod(ro, 0o755)
+    out = tmp_path / "ok"
+    out.mkdir()
+    F.jpeg2ppm(os.path.join(JDIR, name), out / "x.pnm")
+    _check_outputs(out, EXPECT[name])
