@@ -12,6 +12,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -192,7 +193,8 @@ extern "C" int jpeggpu_decode_batch(const jpeggpu_blob_t *jpegs, size_t n, uint8
    if (T > 256) T = 256;
    if (T > n) T = (unsigned)n;
    // chunk: about 256 MiB of coefficients, at least 2 images per thread, at most the batch
-   size_t F = (size_t(256) << 20) / (in_bytes > out_bytes ? in_bytes : out_bytes);
+   static const size_t chunk_bytes = [] { const char *e = getenv("JPEGGPU_BATCH_CHUNK_BYTES"); return e && atoll(e) > 0 ? (size_t)atoll(e) : (size_t(256) << 20); }();
+   size_t F = chunk_bytes / (in_bytes > out_bytes ? in_bytes : out_bytes);
    if (F < 2 * T) F = 2 * T;
    F = (F + T - 1) / T * T;                 // whole rounds of the thread pool
    if (F > 4096) F = 4096;
