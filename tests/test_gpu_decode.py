@@ -378,3 +378,15 @@ def test_jpeg2ppm_reports_a_file_that_cannot_be_written(gpu, tmp_path, name):
     out.mkdir()
     F.jpeg2ppm(os.path.join(JDIR, name), out / "x.pnm")
     _check_outputs(out, EXPECT[name])
+
+
+@pytest.mark.timeout(650)
+def test_host_code_under_address_sanitizer(gpu):
+    """tools/jpeg2ppm_gpu_asan (built by `make -C jpeg-decoder_amd/csrc asan`: the command-line driver and every library source
+    in one program, host code instrumented with AddressSanitizer) decodes every fixture on the GPU, in default steps and
+    in steps of one MCU row -- pools, writer threads, streamed baseline files, damaged inputs: no finding, no hang."""
+    exe = os.path.join(helpers.ROOT, "tools", "jpeg2ppm_gpu_asan")
+    if not os.path.exists(exe):
+        pytest.skip("tools/jpeg2ppm_gpu_asan has not been built")
+    r = subprocess.run(["bash", os.path.join(helpers.ROOT, "tools", "asan_cli.sh")], cwd=helpers.ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " 0 with findings" in r.stdout, (r.stdout[-1500:], r.stderr[-500:])
