@@ -390,3 +390,44 @@ def test_host_code_under_address_sanitizer(gpu):
         pytest.skip("tools/jpeg2ppm_gpu_asan has not been built")
     r = subprocess.run(["bash", os.path.join(helpers.ROOT, "tools", "asan_cli.sh")], cwd=helpers.ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and " 0 with findings" in r.stdout, (r.stdout[-1500:], r.stderr[-500:])
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("kind", ["c2_baseline_444", "c4_progressive_422"])
+def test_full_size_files_against_the_reference_binary(gpu, tmp_path, kind):
+    """BASELINE.json configs[1] and configs[3] as real 4096x4096 files (encoded on the spot with Pillow): the files
+    jpeggpu_jpeg2ppm writes -- one image for the baseline file, one per scan plus the symbolic link for the progressive
+    one -- are byte-identical to those of the reference compiled from its own sources (oracle/_ref/jpeg2ppm_sans_opt,
+    strict IEEE build), run here on the same file."""
+    Image = pytest.importorskip("PIL.Image")
+    from jpeg_decoder_amd import frontend as F
+    ref = os.path.join(helpers.ROOT, "oracle", "_ref", "jpeg2ppm_sans_opt")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/jpeg2ppm_sans_opt has not been built")
+    w = h = 4096
+    rng = np.random.default_rng(41)
+    y, x = np.mgrid[0:h, 0:w]
+    a = np.stack([(x + y) % 256, (x * 3 + y // 2) % 256, (x // 3 + y * 2) % 256], -1).astype(np.float32)
+    a += 50 * np.sin(x / 23.0)[..., None] * np.cos(y / 17.0)[..., None] + rng.normal(0, 10, a.shape).astype(np.float32)
+    b = io.BytesIO()
+    kw = dict(quality=90, subsampling=0) if kind.startswith("c2") else dict(quality=90, subsampling=1, progressive=True)
+    Image.fromarray(np.clip(a, 0, 255).astype(np.uint8)).save(b, "JPEG", **kw)
+    src = tmp_path / "in.jpg"
+    src.write_bytes(b.getvalue())
+    dirs = {}
+    for who in ("ref", "gpu"):
+        dirs[who] = tmp_path / who
+        dirs[who].mkdir()
+    r = subprocess.run([ref, "-o", str(dirs["ref"] / "x.ppm"), str(src)], capture_output=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-300:]
+    F.jpeg2ppm(src, dirs["gpu"] / "x.ppm")
+
+    def listing(d):
+        out = {}
+        for f in sorted(os.listdir(d)):
+            p = os.path.join(d, f)
+            out[f] = ("link", os.readlink(p)) if os.path.islink(p) else ("file", os.path.getsize(p), hashlib.sha256(open(p, "rb").read()).hexdigest())
+        return out
+    got, want = listing(dirs["gpu"]), listing(dirs["ref"])
+    assert len(want) == (1 if kind.startswith("c2") else 11)
+    assert got == want
