@@ -393,9 +393,9 @@ def test_host_code_under_address_sanitizer(gpu):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("kind", ["c2_baseline_444", "c4_progressive_422"])
+@pytest.mark.parametrize("kind", ["c2_baseline_444", "c4_progressive_422", "c3_baseline_420_8192"])
 def test_full_size_files_against_the_reference_binary(gpu, tmp_path, kind):
-    """BASELINE.json configs[1] and configs[3] as real 4096x4096 files (encoded on the spot with Pillow): the files
+    """BASELINE.json configs[1], configs[3] (4096x4096) and configs[2] (8192x8192 4:2:0) as real files (encoded on the spot with Pillow): the files
     jpeggpu_jpeg2ppm writes -- one image for the baseline file, one per scan plus the symbolic link for the progressive
     one -- are byte-identical to those of the reference compiled from its own sources (oracle/_ref/jpeg2ppm_sans_opt,
     strict IEEE build), run here on the same file."""
@@ -404,13 +404,13 @@ def test_full_size_files_against_the_reference_binary(gpu, tmp_path, kind):
     ref = os.path.join(helpers.ROOT, "oracle", "_ref", "jpeg2ppm_sans_opt")
     if not os.path.exists(ref):
         pytest.skip("oracle/_ref/jpeg2ppm_sans_opt has not been built")
-    w = h = 4096
+    w = h = 8192 if kind.startswith("c3") else 4096
     rng = np.random.default_rng(41)
     y, x = np.mgrid[0:h, 0:w]
     a = np.stack([(x + y) % 256, (x * 3 + y // 2) % 256, (x // 3 + y * 2) % 256], -1).astype(np.float32)
     a += 50 * np.sin(x / 23.0)[..., None] * np.cos(y / 17.0)[..., None] + rng.normal(0, 10, a.shape).astype(np.float32)
     b = io.BytesIO()
-    kw = dict(quality=90, subsampling=0) if kind.startswith("c2") else dict(quality=90, subsampling=1, progressive=True)
+    kw = {"c2": dict(quality=90, subsampling=0), "c4": dict(quality=90, subsampling=1, progressive=True), "c3": dict(quality=85, subsampling=2)}[kind[:2]]
     Image.fromarray(np.clip(a, 0, 255).astype(np.uint8)).save(b, "JPEG", **kw)
     src = tmp_path / "in.jpg"
     src.write_bytes(b.getvalue())
@@ -429,5 +429,5 @@ def test_full_size_files_against_the_reference_binary(gpu, tmp_path, kind):
             out[f] = ("link", os.readlink(p)) if os.path.islink(p) else ("file", os.path.getsize(p), hashlib.sha256(open(p, "rb").read()).hexdigest())
         return out
     got, want = listing(dirs["gpu"]), listing(dirs["ref"])
-    assert len(want) == (1 if kind.startswith("c2") else 11)
+    assert len(want) == (11 if kind.startswith("c4") else 1)
     assert got == want
