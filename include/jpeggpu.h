@@ -143,8 +143,9 @@ size_t jpeggpu_raster_row_bytes(const jpeggpu_frame_desc_t *desc);
  * Host-pointer form, synchronous: the frame is cut into stripes of whole MCU rows; all uploads run back to back
  * on one stream, each stripe's kernel and download follow on a second, so that the upload of one stripe, the
  * kernel of the previous and the download of the one before overlap on the full-duplex link (pinned
- * hipMemcpyAsync both ways; see jpeggpu_host_alloc / jpeggpu_host_register below).  With a pageable raster of
- * 16 MiB and more the call starts one helper thread of its own and joins it before it returns.            */
+ * hipMemcpyAsync both ways; see jpeggpu_host_alloc / jpeggpu_host_register below).  With pageable planes or a
+ * pageable raster of 16 MiB and more the call starts a helper thread for that direction's staging copies and
+ * joins it before it returns.                                                                              */
 int jpeggpu_backend_run(const jpeggpu_frame_desc_t *desc,
                         const jpeggpu_blocl16_t *const coef[3],
                         const jpeggpu_qtable_t *const qtables[4],
