@@ -384,7 +384,8 @@ def test_jpeg2ppm_reports_a_file_that_cannot_be_written(gpu, tmp_path, name):
 def test_host_code_under_address_sanitizer(gpu):
     """tools/jpeg2ppm_gpu_asan (built by `make -C jpeg-decoder_amd/csrc asan`: the command-line driver and every library source
     in one program, host code instrumented with AddressSanitizer) decodes every fixture on the GPU, in default steps and
-    in steps of one MCU row -- pools, writer threads, streamed baseline files, damaged inputs: no finding, no hang."""
+    in steps of one MCU row -- pools, writer threads, streamed baseline files, damaged inputs -- and tools/host_pipe_asan
+    (tools/host_pipe_check.cpp, same build) drives the host-pointer entries with their helper threads: no finding, no hang."""
     exe = os.path.join(helpers.ROOT, "tools", "jpeg2ppm_gpu_asan")
     if not os.path.exists(exe):
         pytest.skip("tools/jpeg2ppm_gpu_asan has not been built")
