@@ -74,6 +74,7 @@ struct Tuning {
    uint32_t tile_mcus = 0;       // JPEGGPU_TILE_MCUS: any T (not a power of two: generic pixel phase)
    bool no_uniform = false;      // JPEGGPU_NO_UNIFORM: per-lane prologue everywhere
    bool no_linear = false;       // JPEGGPU_NO_LINEAR: tiles never run on over the end of an MCU row
+   bool no_restage = false;      // JPEGGPU_NO_RESTAGE: never the 16-byte-store pixel phase (kernels.hip, RS)
    size_t stripe_bytes = 0;      // JPEGGPU_STRIPE_BYTES: stripe size of the host-pointer pipeline
    size_t diag_lds_bytes = 0;    // JPEGGPU_DIAG_LDS_BYTES: larger LDS allocation = fewer resident workgroups per CU
    size_t staging_bytes = 0;     // JPEGGPU_DEVICE_STAGING_BYTES: device-side staging of one host-pointer call (0 = 1 GiB)
@@ -88,6 +89,7 @@ void read_tuning() {
    if (const char *e = getenv("JPEGGPU_TILE_MCUS")) t.tile_mcus = (uint32_t)atoi(e);
    t.no_uniform = getenv("JPEGGPU_NO_UNIFORM") != nullptr;
    t.no_linear = getenv("JPEGGPU_NO_LINEAR") != nullptr;
+   t.no_restage = getenv("JPEGGPU_NO_RESTAGE") != nullptr;
    if (const char *e = getenv("JPEGGPU_STRIPE_BYTES")) t.stripe_bytes = (size_t)atoll(e);
    if (const char *e = getenv("JPEGGPU_DIAG_LDS_BYTES")) t.diag_lds_bytes = (size_t)atol(e);
    if (const char *e = getenv("JPEGGPU_DEVICE_STAGING_BYTES")) t.staging_bytes = (size_t)atoll(e);
@@ -348,6 +350,13 @@ int run_device(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, uint32_t nfram
       int rc = ensure_slow_coef(ctx, &p.slow_coef); if (rc) return rc;
    }
    if (nframes > 65535 || d->nbmcuV > 65535) return fail(JPEGGPU_ERR_INVALID_ARG, "nframes / nbmcuV above 65535");
+   // 4:4:4 in full 64-MCU tiles and a 16-byte aligned raster: row-pair units with 16-byte stores (kernels.hip, RS = 1);
+   // the planes then lie in LDS interleaved by row pair
+   if (!tuning().no_restage && !p.slow_coef && !p.linear && p.wave_uniform && d->nbcomp == 3 && p.T == 64 && ld.threads == 192 && fast_colour_layout(p) &&
+       p.hf[1] == 1 && p.vf[1] == 1 && d->width == ld.tiles_per_row * 512 && !(((uintptr_t)d_out | out_stride | out_frame_stride) & 15)) {
+      p.restage = 1;
+      p.plane_off[0] = 0; p.plane_off[1] = 1024; p.plane_off[2] = 2048;
+   }
    if (p.slow_coef && p.linear) { p.linear = 0; ld.tiles_per_row = (d->nbmcuH + p.T - 1) / p.T; ld.mcu_rows = d->nbmcuV; }   // "-f": generic pixel phase
    ld.frames = nframes;
    HIP_TRY(launch_backend(p, ld, s));

@@ -26,6 +26,9 @@
 #ifndef JM_WAVES_PER_EU
 #define JM_WAVES_PER_EU 6
 #endif
+#ifndef JM_RS_WAVES_PER_EU
+#define JM_RS_WAVES_PER_EU 7   // the 4:4:4 restage kernel fits 72 VGPRs without spills: 7 waves per SIMD = 9 workgroups per CU
+#endif
 
 // Raster rows start wherever out_stride puts them (a packed RGB row of odd width is not 4-byte aligned).  gfx950
 // under HSA runs with unaligned dword access enabled, so the 12-byte store is issued at any address.
@@ -174,9 +177,9 @@ __device__ __forceinline__ void pixel_phase_runs(const BackendParams &p, const u
       convert_item<HFC, VFC>(yy, cbw, crw, w);
       if (whole) {
          uint8_t *rowbase = base0 + ((size_t)rowoff + (size_t)y * stride + (size_t)xs * 3);   // wave-uniform
+         typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 #pragma unroll
          for (int v = 0; v < VFC; v++) {
-            typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
             __builtin_nontemporal_store(u32x3{w[v][0], w[v][1], w[v][2]},
                                         reinterpret_cast<u32x3 __attribute__((aligned(JM_STORE_ALIGN))) *>(rowbase + (size_t)v * stride + l12));
          }
@@ -192,6 +195,78 @@ __device__ __forceinline__ void pixel_phase_runs(const BackendParams &p, const u
             for (int v = 0; v < VFC; v++) store_rgb_quad(dst + v * stride, w[v][0], w[v][1], w[v][2], n);
          }
       }
+   }
+}
+
+// ---- 4:4:4 with 16-byte raster stores (RS = 1) ------------------------------------------------------------------
+// What a store INSTRUCTION carries decides the write bandwidth (profiles/r02_ubench_store.txt): 64 lanes x 12 bytes
+// of RGB reach 71.9 % of the HBM peak in c2's shape, 64 x 16 bytes 74 %.  An RGB quad is 12 bytes, so the 16-byte
+// pieces are cut after the conversion: the tile's planes lie in LDS interleaved by ROW PAIR -- unit u = [Y rows 2u,
+// 2u+1 | Cb rows | Cr rows], 3 x 1024 = 3072 contiguous bytes, exactly the size of the unit's RGB output (2 rows x
+// 512 pixels x 3) -- and a whole unit belongs to ONE wave: every lane reads 16 pixels of each plane (3 x
+// ds_read_b128), converts its four quads, writes its 48 bytes back OVER the unit at 48 * lane (the unit's samples
+// are in registers by then, and no other wave ever touches it), reads the pieces [1024 s + 16 lane, + 16), s = 0..2,
+// and stores them: 3 x global_store_dwordx4 of 1024 bytes (the middle one ends row 2u and starts row 2u+1).  No
+// workgroup barrier is involved: LDS serves a wave's instructions in order.  4 units on 3 waves: wave 0 takes two.
+// Host side (plan_backend): 64-MCU tiles that all lie inside the frame (width a multiple of 512), raster base and
+// strides multiples of 16.
+constexpr uint32_t kRsRowBytes = 512, kRsPlaneBytes = 1024, kRsUnitBytes = 3072;
+__device__ __forceinline__ uint32_t special_pair_bits(uint32_t cbw, uint32_t crw) {   // has_special_pair before the compare
+   const uint32_t t = (cbw ^ 0x1C1C1C1Cu) | (crw ^ 0xE4E4E4E4u);
+   return (t - 0x01010101u) & ~t;
+}
+__device__ __forceinline__ void pixel_phase_units444(const BackendParams &p, uint8_t *lds, uint32_t tid, uint32_t tile, uint32_t m, uint32_t frame) {
+   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+   const uint32_t l = tid & 63;
+   const uint32_t stride = (uint32_t)p.out_stride;
+   uint8_t *tile_out = static_cast<uint8_t *>(p.out) + (size_t)frame * p.out_frame_stride + (size_t)m * 8 * p.out_stride + (size_t)tile * (kRsRowBytes * 3);
+   // where a lane's three 16-byte pieces go, relative to the first byte of the unit's first row
+   const uint32_t o0 = l * 16;
+   const uint32_t o1 = l < 32 ? 1024 + l * 16 : stride + (l - 32) * 16;
+   const uint32_t o2 = stride + 512 + l * 16;
+   for (uint32_t u = wave; u < 4; u += 3) {
+      uint8_t *ul = lds + u * kRsUnitBytes;
+      const uint4 yv = *reinterpret_cast<const uint4 *>(ul + l * 16);
+      const uint4 cb = *reinterpret_cast<const uint4 *>(ul + kRsPlaneBytes + l * 16);
+      const uint4 cr = *reinterpret_cast<const uint4 *>(ul + 2 * kRsPlaneBytes + l * 16);
+      const uint32_t yy[4] = { yv.x, yv.y, yv.z, yv.w }, cbw[4] = { cb.x, cb.y, cb.z, cb.w }, crw[4] = { cr.x, cr.y, cr.z, cr.w };
+      uint32_t w[4][3];
+#if defined(JM_DIAG_NOCOLOR)
+#pragma unroll
+      for (int k = 0; k < 4; k++) { w[k][0] = yy[k]; w[k][1] = cbw[k]; w[k][2] = crw[k]; }
+#else
+      const uint32_t sp = (special_pair_bits(cbw[0], crw[0]) | special_pair_bits(cbw[1], crw[1]) | special_pair_bits(cbw[2], crw[2]) |
+                           special_pair_bits(cbw[3], crw[3])) & 0x80808080u;
+      if (__builtin_expect(__any(sp != 0), 0)) {
+         // exact per-pixel form (the y-dependent green offset of (cb,cr) = (28,228))
+#pragma unroll
+         for (int k = 0; k < 4; k++) {
+            uint32_t px[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+               px[i] = ycc_to_rgb((yy[k] >> (8 * i)) & 0xFF, chroma_offsets((cbw[k] >> (8 * i)) & 0xFF, (crw[k] >> (8 * i)) & 0xFF));
+            w[k][0] = px[0] | (px[1] << 24); w[k][1] = (px[1] >> 8) | (px[2] << 16); w[k][2] = (px[2] >> 16) | (px[3] << 8);
+         }
+      } else {
+#pragma unroll
+         for (int k = 0; k < 4; k++) rgb_quad_pk(yy[k], chroma_pairs<1>(cbw[k] ^ 0x80808080u, crw[k] ^ 0x80808080u), w[k]);
+      }
+#endif
+      // every lane's samples are in registers (the values above depend on all three reads) before the first write is issued
+      *reinterpret_cast<u32x4 *>(ul + l * 48) = u32x4{w[0][0], w[0][1], w[0][2], w[1][0]};
+      *reinterpret_cast<u32x4 *>(ul + l * 48 + 16) = u32x4{w[1][1], w[1][2], w[2][0], w[2][1]};
+      *reinterpret_cast<u32x4 *>(ul + l * 48 + 32) = u32x4{w[2][2], w[3][0], w[3][1], w[3][2]};
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const u32x4 s0 = *reinterpret_cast<const u32x4 *>(ul + l * 16);
+      const u32x4 s1 = *reinterpret_cast<const u32x4 *>(ul + 1024 + l * 16);
+      const u32x4 s2 = *reinterpret_cast<const u32x4 *>(ul + 2048 + l * 16);
+      uint8_t *ub = tile_out + (size_t)(2 * u) * stride;      // wave-uniform
+      __builtin_nontemporal_store(s0, reinterpret_cast<u32x4 *>(ub + o0));
+      __builtin_nontemporal_store(s1, reinterpret_cast<u32x4 *>(ub + o1));
+      __builtin_nontemporal_store(s2, reinterpret_cast<u32x4 *>(ub + o2));
    }
 }
 
@@ -318,6 +393,7 @@ __device__ __forceinline__ void pixel_phase(const BackendParams &p, const uint8_
 
 // Phase 1 of one block: both IDCT passes in registers, 8 rows of 8 samples to the component's u8 plane in
 // LDS.  zw = the block's 64 coefficients after iquant, zigzag order, two int16 per word.
+template <int RS>
 __device__ __forceinline__ void transform_block(const uint32_t (&zw)[32], uint8_t *plane, uint32_t pitch) {
    uint2 rows[8];
    {
@@ -334,7 +410,10 @@ __device__ __forceinline__ void transform_block(const uint32_t (&zw)[32], uint8_
 #endif
    }
 #pragma unroll
-   for (int r = 0; r < 8; r++) *reinterpret_cast<uint2 *>(plane + r * pitch) = rows[r];
+   for (int r = 0; r < 8; r++) {
+      if (RS == 1) *reinterpret_cast<uint2 *>(plane + (r >> 1) * kRsUnitBytes + (r & 1) * kRsRowBytes) = rows[r];   // immediate offsets
+      else *reinterpret_cast<uint2 *>(plane + r * pitch) = rows[r];
+   }
 }
 
 // "-f": the direct transform idct (src/idct.c:50-71) instead of idct_opt.  Per sample (x, y) a 64-term
@@ -382,7 +461,7 @@ __device__ __forceinline__ const uint8_t *record_ptr(const BlockCtx &k, uint32_t
 // SGPRs, the table is 32 scalar loads from the kernel arguments, and nothing is staged in LDS.  Otherwise (narrow
 // frames whose tile shrinks, sampling layouts such as 4:1:1 + 2x1 chroma, the JPEGGPU_NO_UNIFORM / _TILE_MCUS knobs)
 // every lane selects its component's fields with v_cndmask and the tables go through LDS.
-template <int HFC, int VFC, bool SLOW>   // chroma factors; 0 = generic path (any factors, any component)
+template <int HFC, int VFC, bool SLOW, int RS = 0>   // chroma factors; 0 = generic path (any factors, any component); RS: restaged 16-byte stores
 __device__ __forceinline__ void backend_body(const BackendParams &p) {
    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
    const uint32_t tid = threadIdx.x, nt = blockDim.x;
@@ -413,7 +492,7 @@ __device__ __forceinline__ void backend_body(const BackendParams &p) {
    long long ts1;
 #endif
 #if !defined(JM_NO_UNIFORM_PATH)
-   if (p.wave_uniform) {
+   if (RS != 0 || p.wave_uniform) {
       const uint32_t wb = __builtin_amdgcn_readfirstlane(tid);   // first block of this wave
       const uint32_t c = (p.nbcomp == 3) ? (uint32_t)(wb >= p.boff[1]) + (uint32_t)(wb >= p.boff[2]) : 0u;
       const uint32_t bw = p.bw[c], nbH = p.nbH[c], vs = p.vs[c];
@@ -502,7 +581,7 @@ __device__ __forceinline__ void backend_body(const BackendParams &p) {
    }
    if (active) {
       if constexpr (SLOW) transform_block_slow(zw, plane, pitch, p.slow_coef);
-      else transform_block(zw, plane, pitch);
+      else transform_block<RS>(zw, plane, pitch);
    }
 
 #if defined(JM_DIAG_STAMP)
@@ -514,6 +593,7 @@ __device__ __forceinline__ void backend_body(const BackendParams &p) {
    const long long ts3 = __builtin_amdgcn_s_memtime();
 #endif
 #if !defined(JM_DIAG_NOPHASE2)
+   if constexpr (RS == 1) { pixel_phase_units444(p, lds, tid, tile, m, frame); return; }
 #if !defined(JM_NO_RUNS)
    if (HFC != 0 && p.wq_shift >= 6) pixel_phase_runs<(HFC ? HFC : 1), (VFC ? VFC : 1)>(p, lds, tid, nt, geo, frame);
    else
@@ -538,6 +618,9 @@ __device__ __forceinline__ void backend_body(const BackendParams &p) {
 template <int HFC, int VFC, int MAXT>
 __global__ void __launch_bounds__(MAXT, JM_WAVES_PER_EU) backend_kernel(const BackendParams p) { backend_body<HFC, VFC, false>(p); }
 
+// 4:4:4 in 64-MCU tiles that all lie inside the frame: pixel phase by row-pair units with 16-byte stores (pixel_phase_units444)
+__global__ void __launch_bounds__(192, JM_RS_WAVES_PER_EU) backend_kernel_rs444(const BackendParams p) { backend_body<1, 1, false, 1>(p); }
+
 // the "-f" variant: generic pixel phase, no occupancy target (the direct transform keeps the block in 64 VGPRs)
 __global__ void __launch_bounds__(JM_MAX_THREADS) backend_kernel_slow(const BackendParams p) { backend_body<0, 0, true>(p); }
 
@@ -551,6 +634,7 @@ bool fast_colour_layout(const BackendParams &p) {
 typedef void (*BackendFn)(const BackendParams);
 static BackendFn pick_kernel(const BackendParams &p, uint32_t threads) {
    if (p.slow_coef) return (BackendFn)backend_kernel_slow;
+   if (p.restage == 1) return (BackendFn)backend_kernel_rs444;
 #define JM_PICK(H, V) (threads <= 256 ? (BackendFn)backend_kernel<H, V, 256> : (BackendFn)backend_kernel<H, V, JM_MAX_THREADS>)
    if (fast_colour_layout(p)) {
       const uint32_t h = p.hf[1], v = p.vf[1];
@@ -567,6 +651,10 @@ hipError_t launch_backend(const BackendParams &p, const LaunchDims &d, hipStream
    dim3 grid(d.tiles_per_row, d.mcu_rows, d.frames), block(d.threads);   // linear tiling: tiles of the frame x 1
    if (d.threads > JM_MAX_THREADS) return hipErrorInvalidConfiguration;
    if (p.linear && (!fast_colour_layout(p) || !p.wave_uniform || p.wq_shift < 6 || d.mcu_rows != 1)) return hipErrorInvalidConfiguration;
+   if (p.restage == 1 && (p.slow_coef || p.linear || !p.wave_uniform || !fast_colour_layout(p) || p.hf[1] != 1 || p.vf[1] != 1 || p.T != 64 || d.threads != 192 ||
+                          p.width != d.tiles_per_row * 512 || p.plane_off[1] != kRsPlaneBytes || p.plane_off[2] != 2 * kRsPlaneBytes ||
+                          (((uintptr_t)p.out | p.out_stride | p.out_frame_stride) & 15) || d.lds_bytes < 4 * kRsUnitBytes))
+      return hipErrorInvalidConfiguration;
    BackendFn k = pick_kernel(p, d.threads);
    if (d.lds_bytes > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d.lds_bytes);

@@ -209,6 +209,47 @@ def test_linear_tiling(gpu, samp):
         assert np.array_equal(outs[0][f], orc.backend_run(d, [host[c][f * nb[c]:(f + 1) * nb[c]] for c in range(3)], QT)), f
 
 
+def test_444_row_pair_units_with_16_byte_stores(gpu):
+    """4:4:4 frames made of whole 64-MCU tiles with a 16-byte aligned raster take backend_kernel_rs444 (planes interleaved by
+    row pair in LDS, RGB restaged inside the wave, 16-byte stores); anything else -- and JPEGGPU_NO_RESTAGE -- the 12-byte
+    runs.  Both against the oracle, several frames per launch, padded rows, the special chroma pair, both iquant modes."""
+    import torch
+    samp = ((1, 1),) * 3
+    for (w, h, nf, pad, aq) in ((512, 8, 1, 0, True), (1024, 24, 3, 16, False), (1536, 13, 2, 48, True), (2048, 40, 1, 7, True), (4096, 16, 2, 0, False)):
+        d = helpers.oracle_desc(w, h, samp, apply_iquant=aq)
+        gd = helpers.to_gpu_desc(gpu, d)
+        nb = helpers.plane_shape(d, 0)[0]
+        host = [pyoracle.synth_blocks(nb * nf, 4400 + 3 * w + c, 0, 0 if aq else 1) for c in range(3)]
+        if w == 1024:      # a run of the special pair (cb, cr) = (28, 228) under every luma value
+            host[0][:256, :] = 0; host[1][:256, :] = 0; host[2][:256, :] = 0
+            host[0][:256, 0] = (np.arange(256) - 128) * 8
+            host[1][:256, 0] = (28 - 128) * 8
+            host[2][:256, 0] = (228 - 128) * 8
+        dev = [torch.from_numpy(a).cuda() for a in host]
+        rows, rb = gpu.raster_rows(gd), gpu.raster_row_bytes(gd)
+        stride = rb + pad
+        outs = []
+        for knob in (None, "1"):
+            if knob:
+                os.environ["JPEGGPU_NO_RESTAGE"] = knob
+            gpu.reload_tuning()
+            try:
+                out = torch.full((nf * rows * stride + 32,), 0x5A, dtype=torch.uint8, device="cuda")
+                torch.cuda.synchronize()
+                gpu.backend_run_batch_device(gd, nf, [t.data_ptr() for t in dev], None, QT, out.data_ptr(), stride, 0)
+                gpu.synchronize()
+                outs.append(out.cpu().numpy())
+            finally:
+                os.environ.pop("JPEGGPU_NO_RESTAGE", None)
+                gpu.reload_tuning()
+        assert np.array_equal(outs[0], outs[1]), (w, h)
+        got = outs[0][:nf * rows * stride].reshape(nf, rows, stride)
+        assert np.all(got[:, :, rb:] == 0x5A) and np.all(outs[0][nf * rows * stride:] == 0x5A)
+        for f in range(nf):
+            want = orc.backend_run(d, [host[c][f * nb:(f + 1) * nb] for c in range(3)], QT)
+            assert np.array_equal(got[f, :, :rb], want), (w, h, f)
+
+
 def test_full_int16_range_and_wrap(gpu):
     d = helpers.oracle_desc(640, 64, ((2, 2), (1, 1), (1, 1)), idq=[2, 2, 2])
     planes = helpers.synth_planes(d, 7, kind=2)

@@ -76,6 +76,58 @@ template <int M> __global__ void __launch_bounds__(192) k(const u32x4 *in, uint8
       }
       return;
    }
+   if (M == 9) {   // row-pair units: 4 units of 2 rows x 1536 B = 3 stores of 64 x 16 B (the middle one half in row A, half in row B);
+      // wave 0 takes units 0 and 3, waves 1 and 2 one unit each.  No LDS.
+      const uint32_t o0 = lane * 16, o1 = lane < 32 ? 1024 + lane * 16 : (uint32_t)stride + (lane - 32) * 16, o2 = (uint32_t)stride + 512 + lane * 16;
+      int k2 = 0;
+      for (uint32_t u = wave; u < 4; u += 3, k2 += 3) {
+         uint8_t *ub = tile_out + 2 * u * stride;
+         __builtin_nontemporal_store(u32x4{w[k2][0], w[k2][1], w[k2 + 1][0], w[k2 + 1][1]}, reinterpret_cast<u32x4 *>(ub + o0));
+         __builtin_nontemporal_store(u32x4{w[k2 + 1][0], w[k2 + 1][1], w[k2 + 2][0], w[k2 + 2][1]}, reinterpret_cast<u32x4 *>(ub + o1));
+         __builtin_nontemporal_store(u32x4{w[k2 + 2][0], w[k2 + 2][1], w[k2][0], w[k2][1]}, reinterpret_cast<u32x4 *>(ub + o2));
+      }
+      return;
+   }
+   if (M == 10 || M == 11) {   // the kernel's skeleton with the wave-private restage: planes interleaved per row pair in LDS
+      // (unit u = [Y rows 2u,2u+1 | Cb | Cr] = 3072 contiguous bytes), barrier, then per unit: every lane reads 3 x 16 bytes
+      // (16 pixels of each plane), writes 48 bytes of "RGB" back over the unit at 48 * lane, reads 16-byte pieces at
+      // 1024 s + 16 lane and stores them.  M11: the same with four runs of 12-byte stores per unit (store shape only).
+      uint8_t *pl = lds + wave * 1024 + lane * 8;
+#pragma unroll
+      for (int r = 0; r < 8; r++) *reinterpret_cast<uint2 *>(pl + (r >> 1) * 3072 + (r & 1) * 512) = make_uint2(w[r][0], w[r][1]);
+      __syncthreads();
+      const uint32_t o0 = lane * 16, o1 = lane < 32 ? 1024 + lane * 16 : (uint32_t)stride + (lane - 32) * 16, o2 = (uint32_t)stride + 512 + lane * 16;
+      for (uint32_t u = wave; u < 4; u += 3) {
+         uint8_t *ul = lds + u * 3072;
+         const u32x4 a = *reinterpret_cast<const u32x4 *>(ul + lane * 16);
+         const u32x4 b = *reinterpret_cast<const u32x4 *>(ul + 1024 + lane * 16);
+         const u32x4 c = *reinterpret_cast<const u32x4 *>(ul + 2048 + lane * 16);
+         uint8_t *ub = tile_out + 2 * u * stride;
+         if (M == 11) {
+            const uint32_t half = lane >> 5, q = (lane & 31) * 48;
+            uint8_t *d = ub + half * stride + q;
+            __builtin_nontemporal_store(u32x3{a.x, b.x, c.x}, reinterpret_cast<u32x3 __attribute__((aligned(4))) *>(d));
+            __builtin_nontemporal_store(u32x3{a.y, b.y, c.y}, reinterpret_cast<u32x3 __attribute__((aligned(4))) *>(d + 12));
+            __builtin_nontemporal_store(u32x3{a.z, b.z, c.z}, reinterpret_cast<u32x3 __attribute__((aligned(4))) *>(d + 24));
+            __builtin_nontemporal_store(u32x3{a.w, b.w, c.w}, reinterpret_cast<u32x3 __attribute__((aligned(4))) *>(d + 36));
+            continue;
+         }
+         // all three reads of every lane are complete before any write of this wave (data dependence through registers)
+         *reinterpret_cast<u32x4 *>(ul + lane * 48) = u32x4{a.x, b.x, c.x, a.y};
+         *reinterpret_cast<u32x4 *>(ul + lane * 48 + 16) = u32x4{b.y, c.y, a.z, b.z};
+         *reinterpret_cast<u32x4 *>(ul + lane * 48 + 32) = u32x4{c.z, a.w, b.w, c.w};
+         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+         __builtin_amdgcn_wave_barrier();
+         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+         const u32x4 s0 = *reinterpret_cast<const u32x4 *>(ul + lane * 16);
+         const u32x4 s1 = *reinterpret_cast<const u32x4 *>(ul + 1024 + lane * 16);
+         const u32x4 s2 = *reinterpret_cast<const u32x4 *>(ul + 2048 + lane * 16);
+         __builtin_nontemporal_store(s0, reinterpret_cast<u32x4 *>(ub + o0));
+         __builtin_nontemporal_store(s1, reinterpret_cast<u32x4 *>(ub + o1));
+         __builtin_nontemporal_store(s2, reinterpret_cast<u32x4 *>(ub + o2));
+      }
+      return;
+   }
    if (M == 1) {
       // 16 runs of 64 quads (row = run / 2, half = run % 2), wave w takes runs w, w+3, ...
       int k2 = 0;
@@ -127,6 +179,9 @@ int main() {
       run<6>("M6 16-byte stores from 64 lanes, rows of 2048 B per tile, 12288 B apart", d, o, wgs / 6 * 6, 6);
       run<7>("M7 M1 without the non-temporal hint", d, o, wgs, 8);
       run<8>("M8 M1, every wave writes whole rows (both halves)", d, o, wgs, 8);
+      run<9>("M9 16-byte stores, row-pair units (3 x 1024 B per unit), waves 2/1/1", d, o, wgs, 8);
+      run<10>("M10 skeleton with wave-private restage in LDS (M9's stores)", d, o, wgs, 8);
+      run<11>("M11 M10's LDS layout, 12-byte stores (16 px per lane)", d, o, wgs, 8);
    }
    return 0;
 }
