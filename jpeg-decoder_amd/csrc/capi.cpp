@@ -352,10 +352,25 @@ int run_device(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, uint32_t nfram
    if (nframes > 65535 || d->nbmcuV > 65535) return fail(JPEGGPU_ERR_INVALID_ARG, "nframes / nbmcuV above 65535");
    // 4:4:4 in full 64-MCU tiles and a 16-byte aligned raster: row-pair units with 16-byte stores (kernels.hip, RS = 1);
    // the planes then lie in LDS interleaved by row pair
+   const bool aligned16 = !(((uintptr_t)d_out | out_stride | out_frame_stride) & 15);
    if (!tuning().no_restage && !p.slow_coef && !p.linear && p.wave_uniform && d->nbcomp == 3 && p.T == 64 && ld.threads == 192 && fast_colour_layout(p) &&
-       p.hf[1] == 1 && p.vf[1] == 1 && d->width == ld.tiles_per_row * 512 && !(((uintptr_t)d_out | out_stride | out_frame_stride) & 15)) {
+       p.hf[1] == 1 && p.vf[1] == 1 && d->width == ld.tiles_per_row * 512 && aligned16) {
       p.restage = 1;
       p.plane_off[0] = 0; p.plane_off[1] = 1024; p.plane_off[2] = 2048;
+   }
+   // 4:2:0 (Y 2x2, Cb and Cr 1x1 on one table), uncropped width, 16-byte aligned raster: 32-MCU tiles of 192 lanes, Cb and
+   // Cr sharing the third wave (kernels.hip, RS = 2); frames whose MCU rows are not a whole number of tiles are tiled linearly
+   if (!tuning().no_restage && !tuning().tile_mcus && !tuning().target_blocks && !tuning().no_uniform && !p.slow_coef && d->nbcomp == 3 &&
+       d->comp[0].hs == 2 && d->comp[0].vs == 2 && d->comp[1].hs == 1 && d->comp[1].vs == 1 && d->comp[2].hs == 1 && d->comp[2].vs == 1 && d->max_h == 2 && d->max_v == 2 &&
+       (!d->apply_iquant || d->comp[1].idq == d->comp[2].idq) && d->nbmcuH >= 32 && d->width == (uint32_t)d->nbmcuH * 16 && aligned16 &&
+       (uint64_t)d->nbmcuH * d->nbmcuV < (1ull << 31) && (d->nbmcuH % 32 == 0 || !tuning().no_linear)) {
+      p.restage = 2;
+      p.T = 32; p.B = 192;
+      p.linear = d->nbmcuH % 32 != 0;
+      ld.threads = 192;
+      ld.lds_bytes = 12288;
+      ld.tiles_per_row = p.linear ? (p.total_mcus + 31) / 32 : d->nbmcuH / 32;
+      ld.mcu_rows = p.linear ? 1 : d->nbmcuV;
    }
    if (p.slow_coef && p.linear) { p.linear = 0; ld.tiles_per_row = (d->nbmcuH + p.T - 1) / p.T; ld.mcu_rows = d->nbmcuV; }   // "-f": generic pixel phase
    ld.frames = nframes;

@@ -621,6 +621,181 @@ __global__ void __launch_bounds__(MAXT, JM_WAVES_PER_EU) backend_kernel(const Ba
 // 4:4:4 in 64-MCU tiles that all lie inside the frame: pixel phase by row-pair units with 16-byte stores (pixel_phase_units444)
 __global__ void __launch_bounds__(192, JM_RS_WAVES_PER_EU) backend_kernel_rs444(const BackendParams p) { backend_body<1, 1, false, 1>(p); }
 
+// ---- 4:2:0 in 32-MCU tiles with 16-byte stores (RS = 2) -----------------------------------------------------------
+// The general kernel needs 64 MCUs = 384 lanes per tile to keep every wave on one component, which leaves room for
+// four workgroups per CU.  Here a tile is 32 MCUs = 192 lanes: waves 0 and 1 hold the two block rows of Y (64 blocks
+// each), wave 2 holds Cb in lanes 0..31 and Cr in lanes 32..63 -- both are 1x1 components of equal geometry and (host
+// check) share a quantisation table, so the two differ in one 64-bit base address per lane.  Free of the generic
+// paths the kernel fits 72 VGPRs: 9 workgroups per CU.
+// LDS: unit u = raster rows 2u, 2u+1 of the tile = [Y row 2u (512 B) | Y row 2u+1 (512 B) | Cb row u (256 B) | Cr row u
+// (256 B)] = 1536 bytes, 8 units.  Phase 2: a unit belongs to one wave; lane l reads 8 pixels x 2 rows (two ds_read_b64
+// of Y, one dword of each chroma plane), converts, and the unit's 1536 bytes become the staging of ONE raster row at a
+// time (row 2u: 24 bytes per lane in, 16-byte pieces out; then row 2u+1), so that the stores are the three of the
+// 4:4:4 kernel: 1024 B of row 2u | 512 B of row 2u + 512 B of row 2u+1 | 1024 B of row 2u+1.  8 units on 3 waves.
+// Linear tiling (frames whose MCU rows are not a whole number of tiles): a 16-byte piece never straddles an MCU (48
+// bytes), so the wrap into the next MCU row is a per-lane choice between two offsets, made once per tile.
+constexpr uint32_t kR2Unit = 1536, kR2Cb = 1024, kR2Cr = 1280;
+#ifndef JM_R2_WAVES_PER_EU
+#define JM_R2_WAVES_PER_EU 6
+#endif
+__global__ void __launch_bounds__(192, JM_R2_WAVES_PER_EU) backend_kernel_rs420(const BackendParams p) {
+   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+   const uint32_t tid = threadIdx.x;
+   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+   const uint32_t frame = blockIdx.z;
+   uint32_t m0, c0, wrapj, nvalid;
+   if (p.linear) {
+      const uint32_t g0 = blockIdx.x * 32;
+      m0 = g0 / p.nbmcuH; c0 = g0 - m0 * p.nbmcuH; wrapj = p.nbmcuH - c0; nvalid = min(32u, p.total_mcus - g0);
+   } else {
+      m0 = blockIdx.y; c0 = blockIdx.x * 32; wrapj = 0x7FFFFFFFu; nvalid = 32;
+   }
+   // ---- phase 1 ----
+   uint32_t zw[32];
+   {
+      const uint32_t l = tid & 63;
+      const uint4 *src;
+      uint32_t idq;
+      if (wave < 2) {      // Y: block row `wave` of the MCU row, 64 blocks
+         const uint32_t nbH = p.nbH[0], j = l >> 1;
+         const bool r2 = j >= wrapj && j < nvalid;
+         uint32_t col = r2 ? l - (wrapj << 1) : (c0 << 1) + l;
+         col = min(col, nbH - 1);
+         const uint8_t *base = static_cast<const uint8_t *>(p.coef[0]) + (size_t)frame * p.coef_frame_stride[0] + (size_t)m0 * 2 * nbH * 128;
+         src = reinterpret_cast<const uint4 *>(base + (((r2 ? 2u : 0u) + wave) * nbH + col) * 128u);
+         idq = p.idq[0];
+      } else {             // Cb | Cr
+         const uint32_t nbH = p.nbH[1], j = l & 31;
+         const bool r2 = j >= wrapj && j < nvalid;
+         uint32_t col = r2 ? j - wrapj : c0 + j;
+         col = min(col, nbH - 1);
+         const uint8_t *b1 = static_cast<const uint8_t *>(p.coef[1]) + (size_t)frame * p.coef_frame_stride[1] + (size_t)m0 * nbH * 128;
+         const uint8_t *b2 = static_cast<const uint8_t *>(p.coef[2]) + (size_t)frame * p.coef_frame_stride[2] + (size_t)m0 * nbH * 128;
+         src = reinterpret_cast<const uint4 *>((l < 32 ? b1 : b2) + ((r2 ? nbH : 0u) + col) * 128u);
+         idq = p.idq[1];
+      }
+      uint4 v[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[i] = src[i];
+      if (p.apply_iquant) {
+         const uint32_t *q = p.qt[idq];
+#pragma unroll
+         for (int i = 0; i < 8; i++) {
+            zw[4 * i] = iquant_word(v[i].x, q[4 * i]); zw[4 * i + 1] = iquant_word(v[i].y, q[4 * i + 1]);
+            zw[4 * i + 2] = iquant_word(v[i].z, q[4 * i + 2]); zw[4 * i + 3] = iquant_word(v[i].w, q[4 * i + 3]);
+         }
+      } else {
+#pragma unroll
+         for (int i = 0; i < 8; i++) { zw[4 * i] = v[i].x; zw[4 * i + 1] = v[i].y; zw[4 * i + 2] = v[i].z; zw[4 * i + 3] = v[i].w; }
+      }
+   }
+   {
+      uint2 rows[8];
+      {
+         f32x2 mtx[4][8];
+         izz_rp(zw, mtx);
+#if defined(JM_DIAG_NOIDCT)
+#pragma unroll
+         for (int r = 0; r < 8; r++) { float u[8];
+#pragma unroll
+            for (int c2 = 0; c2 < 8; c2++) u[c2] = (c2 & 1) ? mtx[c2 >> 1][r].y : mtx[c2 >> 1][r].x;
+            rows[r] = pack_row(u); }
+#else
+         idct_block_rp(mtx, rows);
+#endif
+      }
+      // Y wave w, block row r -> raster row R = 8 w + r of the tile: unit R >> 1, its row R & 1; chroma row r -> unit r.
+      // Both are pl + (r >> 1) * U + (r & 1) * V with wave-uniform U, V (lanes 32..63 of the chroma wave: kR2Cb + 256 + ... = kR2Cr + ...)
+      const uint32_t U = wave < 2 ? kR2Unit : 2 * kR2Unit, V = wave < 2 ? 512u : kR2Unit;
+      uint8_t *pl = lds + (wave < 2 ? wave * (4 * kR2Unit) : kR2Cb) + (tid & 63) * 8;
+#pragma unroll
+      for (int r = 0; r < 8; r++) *reinterpret_cast<uint2 *>(pl + ((r >> 1) * U + (r & 1) * V)) = rows[r];
+   }
+   __syncthreads();
+#if !defined(JM_DIAG_NOPHASE2)
+   // ---- phase 2 ----
+   const uint32_t l = tid & 63;
+   const uint32_t stride = (uint32_t)p.out_stride;
+   const uint32_t band = 16 * stride;
+   // the three pieces of a lane: (row of the unit, byte offset in the tile's 1536-byte row)
+   const uint32_t b0 = l * 16, b1 = (l * 16 + 1024) % kR2Unit, b2 = 512 + l * 16;
+   const uint32_t r1 = l < 32 ? 0u : stride;
+   uint32_t o0, o1, o2;
+   bool ok0 = true, ok1 = true, ok2 = true;
+   if (p.linear) {
+      // MCU of a piece = byte / 48; before the wrap it lies c0 MCUs into MCU row m0, after it at the start of the next one
+      const uint32_t j0 = b0 / 48, j1 = b1 / 48, j2 = b2 / 48;
+      const uint32_t before = c0 * 48, after = band - wrapj * 48;
+      o0 = b0 + (j0 < wrapj ? before : after); ok0 = j0 < nvalid;
+      o1 = b1 + (j1 < wrapj ? before : after) + r1; ok1 = j1 < nvalid;
+      o2 = b2 + (j2 < wrapj ? before : after) + stride; ok2 = j2 < nvalid;
+   } else {
+      o0 = c0 * 48 + b0; o1 = c0 * 48 + b1 + r1; o2 = c0 * 48 + b2 + stride;
+   }
+   uint8_t *tile_out = static_cast<uint8_t *>(p.out) + (size_t)frame * p.out_frame_stride + (size_t)m0 * band;
+   for (uint32_t u = wave; u < 8; u += 3) {
+      uint8_t *ul = lds + u * kR2Unit;
+      const uint2 ya = *reinterpret_cast<const uint2 *>(ul + l * 8);
+      const uint2 yb = *reinterpret_cast<const uint2 *>(ul + 512 + l * 8);
+      const uint32_t cbw = *reinterpret_cast<const uint32_t *>(ul + kR2Cb + l * 4);
+      const uint32_t crw = *reinterpret_cast<const uint32_t *>(ul + kR2Cr + l * 4);
+      uint32_t wa[2][3], wb[2][3];      // rows 2u and 2u+1, two quads each
+#if defined(JM_DIAG_NOCOLOR)
+      wa[0][0] = ya.x; wa[0][1] = cbw; wa[0][2] = crw; wa[1][0] = ya.y; wa[1][1] = cbw; wa[1][2] = crw;
+      wb[0][0] = yb.x; wb[0][1] = cbw; wb[0][2] = crw; wb[1][0] = yb.y; wb[1][1] = cbw; wb[1][2] = crw;
+#else
+      if (__builtin_expect(__any(has_special_pair(cbw, crw)), 0)) {
+#pragma unroll
+         for (int q = 0; q < 2; q++) {
+            uint32_t pa[4], pb[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+               const int ci = 2 * q + (i >> 1);
+               const ChromaOff co = chroma_offsets((cbw >> (8 * ci)) & 0xFF, (crw >> (8 * ci)) & 0xFF);
+               pa[i] = ycc_to_rgb(((q ? ya.y : ya.x) >> (8 * i)) & 0xFF, co);
+               pb[i] = ycc_to_rgb(((q ? yb.y : yb.x) >> (8 * i)) & 0xFF, co);
+            }
+            wa[q][0] = pa[0] | (pa[1] << 24); wa[q][1] = (pa[1] >> 8) | (pa[2] << 16); wa[q][2] = (pa[2] >> 16) | (pa[3] << 8);
+            wb[q][0] = pb[0] | (pb[1] << 24); wb[q][1] = (pb[1] >> 8) | (pb[2] << 16); wb[q][2] = (pb[2] >> 16) | (pb[3] << 8);
+         }
+      } else {
+         const uint32_t cbs = cbw ^ 0x80808080u, crs = crw ^ 0x80808080u;
+         const ChromaPairs oa = chroma_pairs<2>(cbs, crs), ob = chroma_pairs<2>(cbs >> 16, crs >> 16);
+         rgb_quad_pk(ya.x, oa, wa[0]); rgb_quad_pk(ya.y, ob, wa[1]);
+         rgb_quad_pk(yb.x, oa, wb[0]); rgb_quad_pk(yb.y, ob, wb[1]);
+      }
+#endif
+      uint8_t *ub = tile_out + (size_t)(2 * u) * stride;      // wave-uniform
+      // row 2u through the unit's own 1536 bytes (every lane's samples are in registers: wa / wb depend on all four reads)
+      *reinterpret_cast<uint2 *>(ul + l * 24) = make_uint2(wa[0][0], wa[0][1]);
+      *reinterpret_cast<uint2 *>(ul + l * 24 + 8) = make_uint2(wa[0][2], wa[1][0]);
+      *reinterpret_cast<uint2 *>(ul + l * 24 + 16) = make_uint2(wa[1][1], wa[1][2]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const u32x4 s0 = *reinterpret_cast<const u32x4 *>(ul + b0);
+      u32x4 s1 = u32x4{0, 0, 0, 0};
+      if (l < 32) s1 = *reinterpret_cast<const u32x4 *>(ul + b1);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // row 2u+1
+      *reinterpret_cast<uint2 *>(ul + l * 24) = make_uint2(wb[0][0], wb[0][1]);
+      *reinterpret_cast<uint2 *>(ul + l * 24 + 8) = make_uint2(wb[0][2], wb[1][0]);
+      *reinterpret_cast<uint2 *>(ul + l * 24 + 16) = make_uint2(wb[1][1], wb[1][2]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (l >= 32) s1 = *reinterpret_cast<const u32x4 *>(ul + b1);
+      const u32x4 s2 = *reinterpret_cast<const u32x4 *>(ul + b2);
+      if (ok0) __builtin_nontemporal_store(s0, reinterpret_cast<u32x4 *>(ub + o0));
+      if (ok1) __builtin_nontemporal_store(s1, reinterpret_cast<u32x4 *>(ub + o1));
+      if (ok2) __builtin_nontemporal_store(s2, reinterpret_cast<u32x4 *>(ub + o2));
+   }
+#endif
+}
+
 // the "-f" variant: generic pixel phase, no occupancy target (the direct transform keeps the block in 64 VGPRs)
 __global__ void __launch_bounds__(JM_MAX_THREADS) backend_kernel_slow(const BackendParams p) { backend_body<0, 0, true>(p); }
 
@@ -635,6 +810,7 @@ typedef void (*BackendFn)(const BackendParams);
 static BackendFn pick_kernel(const BackendParams &p, uint32_t threads) {
    if (p.slow_coef) return (BackendFn)backend_kernel_slow;
    if (p.restage == 1) return (BackendFn)backend_kernel_rs444;
+   if (p.restage == 2) return (BackendFn)backend_kernel_rs420;
 #define JM_PICK(H, V) (threads <= 256 ? (BackendFn)backend_kernel<H, V, 256> : (BackendFn)backend_kernel<H, V, JM_MAX_THREADS>)
    if (fast_colour_layout(p)) {
       const uint32_t h = p.hf[1], v = p.vf[1];
@@ -650,7 +826,13 @@ static BackendFn pick_kernel(const BackendParams &p, uint32_t threads) {
 hipError_t launch_backend(const BackendParams &p, const LaunchDims &d, hipStream_t s) {
    dim3 grid(d.tiles_per_row, d.mcu_rows, d.frames), block(d.threads);   // linear tiling: tiles of the frame x 1
    if (d.threads > JM_MAX_THREADS) return hipErrorInvalidConfiguration;
-   if (p.linear && (!fast_colour_layout(p) || !p.wave_uniform || p.wq_shift < 6 || d.mcu_rows != 1)) return hipErrorInvalidConfiguration;
+   if (p.restage != 2 && p.linear && (!fast_colour_layout(p) || !p.wave_uniform || p.wq_shift < 6 || d.mcu_rows != 1)) return hipErrorInvalidConfiguration;
+   if (p.restage == 2 && (p.slow_coef || p.nbcomp != 3 || p.T != 32 || d.threads != 192 || p.hf[0] != 1 || p.vf[0] != 1 || p.hf[1] != 2 || p.vf[1] != 2 ||
+                          p.hf[2] != 2 || p.vf[2] != 2 || p.nbH[0] != 2 * p.nbmcuH || p.nbH[1] != p.nbmcuH || p.nbH[2] != p.nbmcuH ||
+                          p.width != p.nbmcuH * 16 || p.nbmcuH < 32 || (p.apply_iquant && p.idq[1] != p.idq[2]) ||
+                          (p.linear ? (d.mcu_rows != 1 || d.tiles_per_row != (p.total_mcus + 31) / 32) : (p.nbmcuH % 32 != 0 || d.tiles_per_row != p.nbmcuH / 32)) ||
+                          (((uintptr_t)p.out | p.out_stride | p.out_frame_stride) & 15) || d.lds_bytes < 8 * kR2Unit))
+      return hipErrorInvalidConfiguration;
    if (p.restage == 1 && (p.slow_coef || p.linear || !p.wave_uniform || !fast_colour_layout(p) || p.hf[1] != 1 || p.vf[1] != 1 || p.T != 64 || d.threads != 192 ||
                           p.width != d.tiles_per_row * 512 || p.plane_off[1] != kRsPlaneBytes || p.plane_off[2] != 2 * kRsPlaneBytes ||
                           (((uintptr_t)p.out | p.out_stride | p.out_frame_stride) & 15) || d.lds_bytes < 4 * kRsUnitBytes))

@@ -209,22 +209,33 @@ def test_linear_tiling(gpu, samp):
         assert np.array_equal(outs[0][f], orc.backend_run(d, [host[c][f * nb[c]:(f + 1) * nb[c]] for c in range(3)], QT)), f
 
 
-def test_444_row_pair_units_with_16_byte_stores(gpu):
-    """4:4:4 frames made of whole 64-MCU tiles with a 16-byte aligned raster take backend_kernel_rs444 (planes interleaved by
-    row pair in LDS, RGB restaged inside the wave, 16-byte stores); anything else -- and JPEGGPU_NO_RESTAGE -- the 12-byte
-    runs.  Both against the oracle, several frames per launch, padded rows, the special chroma pair, both iquant modes."""
+RS_CASES = {
+    # (width, height, frames, row padding, apply_iquant)
+    "444": (((1, 1),) * 3, [(512, 8, 1, 0, True), (1024, 24, 3, 16, False), (1536, 13, 2, 48, True), (2048, 40, 1, 7, True), (4096, 16, 2, 0, False)]),
+    "420": (((2, 2), (1, 1), (1, 1)), [(512, 16, 1, 0, True), (1024, 40, 3, 16, False), (1920, 1080, 2, 0, True), (1040, 50, 2, 32, True),
+                                     (528, 33, 3, 0, False), (2048, 64, 1, 7, True), (8192, 32, 1, 0, True), (496, 16, 1, 0, True)]),
+}
+
+
+@pytest.mark.parametrize("layout", sorted(RS_CASES))
+def test_restaged_kernels_with_16_byte_stores(gpu, layout):
+    """4:4:4 frames made of whole 64-MCU tiles take backend_kernel_rs444, uncropped 4:2:0 frames backend_kernel_rs420 (32-MCU
+    tiles, Cb and Cr sharing a wave, linear tiling when an MCU row is not a whole number of tiles) -- both with the RGB restaged
+    inside the wave and 16-byte stores, and only when the raster is 16-byte aligned; anything else, and JPEGGPU_NO_RESTAGE, the
+    general kernel.  Both against the oracle: several frames per launch, padded rows, the special chroma pair, both iquant modes."""
     import torch
-    samp = ((1, 1),) * 3
-    for (w, h, nf, pad, aq) in ((512, 8, 1, 0, True), (1024, 24, 3, 16, False), (1536, 13, 2, 48, True), (2048, 40, 1, 7, True), (4096, 16, 2, 0, False)):
+    samp, cases = RS_CASES[layout]
+    for (w, h, nf, pad, aq) in cases:
         d = helpers.oracle_desc(w, h, samp, apply_iquant=aq)
         gd = helpers.to_gpu_desc(gpu, d)
-        nb = helpers.plane_shape(d, 0)[0]
-        host = [pyoracle.synth_blocks(nb * nf, 4400 + 3 * w + c, 0, 0 if aq else 1) for c in range(3)]
-        if w == 1024:      # a run of the special pair (cb, cr) = (28, 228) under every luma value
-            host[0][:256, :] = 0; host[1][:256, :] = 0; host[2][:256, :] = 0
-            host[0][:256, 0] = (np.arange(256) - 128) * 8
-            host[1][:256, 0] = (28 - 128) * 8
-            host[2][:256, 0] = (228 - 128) * 8
+        nb = [helpers.plane_shape(d, c)[0] for c in range(3)]
+        host = [pyoracle.synth_blocks(nb[c] * nf, 4400 + 3 * w + c, 0, 0 if aq else 1) for c in range(3)]
+        if w == 1024:      # the special pair (cb, cr) = (28, 228) under a ramp of luma values
+            for c in range(3):
+                host[c][:nb[c], :] = 0
+            host[0][:nb[0], 0] = ((np.arange(nb[0]) % 256) - 128) * 8
+            host[1][:nb[1], 0] = (28 - 128) * 8
+            host[2][:nb[2], 0] = (228 - 128) * 8
         dev = [torch.from_numpy(a).cuda() for a in host]
         rows, rb = gpu.raster_rows(gd), gpu.raster_row_bytes(gd)
         stride = rb + pad
@@ -246,7 +257,7 @@ def test_444_row_pair_units_with_16_byte_stores(gpu):
         got = outs[0][:nf * rows * stride].reshape(nf, rows, stride)
         assert np.all(got[:, :, rb:] == 0x5A) and np.all(outs[0][nf * rows * stride:] == 0x5A)
         for f in range(nf):
-            want = orc.backend_run(d, [host[c][f * nb:(f + 1) * nb] for c in range(3)], QT)
+            want = orc.backend_run(d, [host[c][f * nb[c]:(f + 1) * nb[c]] for c in range(3)], QT)
             assert np.array_equal(got[f, :, :rb], want), (w, h, f)
 
 
