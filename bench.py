@@ -253,6 +253,212 @@ def end_to_end(jg, np, d, qt, w, h, reps=3):
     return res
 
 
+def measure(jg, workload, frames, steps, warmup, prewarm_ms, strong, images, rank, world, dry_run, host_collectives=False, verify=False):
+    """W warm-up steps, then exactly `steps` timed steps of `workload` (barrier + synchronize on both sides, HIP events around
+    every launch on the launch stream).  Returns the raw figures; the caller turns them into the JSON line."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from jpeg_decoder_amd import sharding, synth
+    desc_text, w, h, samp, nf_default = WORKLOADS[workload]
+    nf = frames or nf_default
+    d = jg.make_desc(w, h, samp)              # host-only geometry
+    full_rows = d.nbmcuV
+    qt = synth.shaun_qtables()
+
+    # ---- what this rank does in one step -------------------------------------------------------------
+    # launches: list of frame counts; every launch works on its own buffers
+    if strong and workload == "c5":
+        my_images = sharding.shard_images(images, rank, world)           # image i -> rank i mod N
+        launches = [min(nf, len(my_images) - i) for i in range(0, len(my_images), nf)]
+        total_pixels_per_step = images * w * h                            # whole job, all ranks
+        shard_text = f"strong: {images} independent images, image i on rank i mod {world}, {len(my_images)} on this rank in launches of {nf}; no collective"
+    elif strong:
+        m0, m1 = sharding.shard_mcu_rows(full_rows, rank, world)               # MCU-row stripe of every frame
+        d.nbmcuV = m1 - m0
+        launches = [nf] if m1 > m0 else []
+        total_pixels_per_step = nf * w * h
+        shard_text = f"strong: {nf} frames per step cut into MCU-row stripes, rank g decodes rows [g*{full_rows}/{world}, (g+1)*{full_rows}/{world}); no collective"
+    else:
+        launches = [nf]
+        total_pixels_per_step = world * nf * w * h
+        shard_text = "weak: independent images per rank, no collective"
+    nb = [jg.plane_blocks(d, c) for c in range(d.nbcomp)]
+    rows, rb = jg.raster_rows(d), jg.raster_row_bytes(d)
+    frames_resident = sum(launches)
+    bytes_per_frame = algorithmic_bytes(jg, d)
+
+    kernel_ms, t_local, sha = [], 0.0, None
+    if dry_run:
+        t_local = 1e-3 * steps * max(1, len(launches))
+        kernel_ms = [1.0] * (steps * max(1, len(launches)))
+    elif launches:
+        # distinct synthetic frames, generated on the device (synth.synth_blocks_torch: the bytes of synth.synth_blocks);
+        # beyond KMAX the buffers repeat frame f mod KMAX -- every frame still has its own memory
+        KMAX = 512
+        kdist = min(frames_resident, KMAX)
+        planes = []
+        for c in range(d.nbcomp):      # frame f of this rank = blocks [(rank * frames + f) * nb, + nb) of component c's stream
+            t = torch.empty((frames_resident * nb[c], 64), dtype=torch.int16, device="cuda")
+            t[:kdist * nb[c]] = synth.synth_blocks_torch(kdist * nb[c], 0x5EED0000 + c, rank * frames_resident * nb[c], 0, "cuda", 1 << 19)
+            for f0 in range(kdist, frames_resident, kdist):
+                n = min(kdist, frames_resident - f0) * nb[c]
+                t[f0 * nb[c]:f0 * nb[c] + n] = t[:n]
+            planes.append(t)
+        out = torch.empty(frames_resident * rows * rb, dtype=torch.uint8, device="cuda")
+        stream = torch.cuda.Stream()      # a real (non-NULL) HIP stream: kernels AND events go on it
+        firsts = [sum(launches[:i]) for i in range(len(launches))]
+
+        def launch(i):
+            f0 = firsts[i]
+            jg.backend_run_batch_device(d, launches[i], [planes[c].data_ptr() + f0 * nb[c] * 128 for c in range(d.nbcomp)], None, qt,
+                                        out.data_ptr() + f0 * rows * rb, 0, 0, stream.cuda_stream)
+
+        def step():
+            for i in range(len(launches)):
+                launch(i)
+
+        def fence():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        t_pre = time.perf_counter()
+        while (time.perf_counter() - t_pre) * 1e3 < prewarm_ms:
+            for _ in range(max(1, 20 // len(launches))):
+                step()
+            torch.cuda.synchronize()
+        for _ in range(warmup):
+            step()
+        fence()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps * len(launches))]
+        t0 = time.perf_counter()
+        k = 0
+        for _ in range(steps):
+            for i in range(len(launches)):
+                a, b = ev[k]
+                k += 1
+                a.record(stream)
+                launch(i)
+                b.record(stream)
+        torch.cuda.synchronize()
+        t_local = time.perf_counter() - t0
+        fence()
+        kernel_ms = [a.elapsed_time(b) for a, b in ev]
+        if verify:      # what the tests compare with the oracle: this rank's first raster
+            import hashlib
+            sha = hashlib.sha256(out[:rows * rb].cpu().numpy().tobytes()).hexdigest()
+        del planes, out
+        torch.cuda.empty_cache()
+    if world > 1:
+        dev = "cpu" if dry_run or host_collectives else "cuda"
+        tt = torch.tensor([t_local], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_max = float(tt.item())
+        mine = torch.tensor([float(np.mean(kernel_ms)) * 1e3 if kernel_ms else 0.0], dtype=torch.float64, device=dev)
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+        per_rank_us = [round(float(x.item()), 2) for x in per_rank]
+        shas = [None] * world
+        if verify:
+            dist.all_gather_object(shas, sha)
+    else:
+        t_max = t_local
+        per_rank_us = [round(float(np.mean(kernel_ms)) * 1e3, 2)]
+        shas = [sha]
+    return dict(first_raster_sha256=shas, desc_text=desc_text, w=w, h=h, samp=samp, nf=nf, desc=d, qt=qt, launches=launches, kernel_ms=kernel_ms, t_max=t_max,
+                per_rank_us=per_rank_us, total_pixels_per_step=total_pixels_per_step, shard_text=shard_text, nb=nb,
+                frames_resident=frames_resident, bytes_per_frame=bytes_per_frame)
+
+
+def roofline_of(m):
+    """(launch seconds, bytes per launch, achieved GB/s) of the full-size launches of one measure()."""
+    import numpy as np
+    launches, kernel_ms = m["launches"], m["kernel_ms"]
+    full = [ms for j, ms in enumerate(kernel_ms) if launches and launches[j % len(launches)] == max(launches)]
+    launch_s = float(np.mean(full)) / 1e3 if full else float("nan")
+    bytes_per_launch = (max(launches) if launches else 0) * m["bytes_per_frame"]
+    achieved = bytes_per_launch / launch_s / 1e9 if full else 0.0
+    return full, launch_s, bytes_per_launch, achieved
+
+
+def other_workloads(jg, steps=10):
+    """The other GPU configurations of BASELINE.json (configs[2..4]) and ONE c2 frame per launch, each for a few steps on
+    this box, so that every configuration is timed by whoever runs the default bench line.  Never part of `value`."""
+    import torch
+    res = {}
+    for wl in ("c3", "c4", "c5"):
+        m = measure(jg, wl, 0, steps, 2, 300.0, False, 0, 0, 1, False)
+        full, launch_s, bpl, achieved = roofline_of(m)
+        res[wl] = {"workload": WORKLOADS[wl][0], "frames_per_launch": m["nf"], "steps": steps, "avg_launch_us": round(launch_s * 1e6, 2),
+                   "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                   "MPix_s": round(m["nf"] * m["w"] * m["h"] / launch_s / 1e6, 1)}
+    # configs[1] read literally: ONE 4096x4096 4:4:4 frame per launch (16 resident frames in turn, so that the 256 MB
+    # Infinity Cache cannot serve it): launches back to back, and launch + synchronise after every frame
+    from jpeg_decoder_amd import synth
+    desc_text, w, h, samp, _ = WORKLOADS["c2"]
+    d = jg.make_desc(w, h, samp)
+    qt = synth.shaun_qtables()
+    nb = [jg.plane_blocks(d, c) for c in range(3)]
+    rows, rb = jg.raster_rows(d), jg.raster_row_bytes(d)
+    K = 16
+    planes = [torch.cat([synth.synth_blocks_torch(nb[c], 0x5EED0000 + c, f * nb[c], 0, "cuda", 1 << 19) for f in range(K)]) for c in range(3)]
+    out = torch.empty(K * rows * rb, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.Stream()
+
+    def launch(f):
+        jg.backend_run_batch_device(d, 1, [planes[c].data_ptr() + f * nb[c] * 128 for c in range(3)], None, qt, out.data_ptr() + f * rows * rb,
+                                    0, 0, stream.cuda_stream)
+    for f in range(4 * K):
+        launch(f % K)
+    torch.cuda.synchronize()
+    n = 20 * K
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for f in range(n):
+        launch(f % K)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    b2b = e0.elapsed_time(e1) * 1e-3 / n
+    t0 = time.perf_counter()
+    for f in range(n):
+        launch(f % K)
+        stream.synchronize()
+    lat = (time.perf_counter() - t0) / n
+    fb = algorithmic_bytes(jg, d)
+    res["c2_one_frame_per_launch"] = {
+        "workload": "one 4096x4096 4:4:4 frame per launch (4096 workgroups on 2304 resident slots: ramp-up and drain are not amortised)",
+        "back_to_back_us": round(b2b * 1e6, 2), "back_to_back_frac": round(fb / b2b / 1e9 / HBM_PEAK_GBPS, 4),
+        "launch_and_sync_us": round(lat * 1e6, 2), "launch_and_sync_frac": round(fb / lat / 1e9 / HBM_PEAK_GBPS, 4)}
+    del planes, out
+    torch.cuda.empty_cache()
+    return res
+
+
+def visible_gpu_count():
+    """GPUs this process would see, WITHOUT touching the HIP/HSA runtime (the parent of the ranks must stay clear of the GPU):
+    the *_VISIBLE_DEVICES lists if set, else the kfd topology nodes that have SIMDs."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    n = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(base):
+            try:
+                with open(os.path.join(base, node, "properties")) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+                if int(props.get("simd_count", "0")) > 0:
+                    n += 1
+            except (OSError, ValueError):
+                pass
+    except OSError:
+        return None
+    return n
+
+
 def spawn_ranks(args):
     """No launcher around us: start the N ranks as children (nothing here has touched a GPU yet) and pass their
     status on."""
@@ -278,6 +484,11 @@ def main():
     ap.add_argument("--images", type=int, default=8192, help="strong scaling of c5: images in the whole job")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the short runs of c3, c4, c5 and of one c2 frame per launch")
+    ap.add_argument("--share-device", action="store_true",
+                    help="N > 1 ranks on ONE GPU (device 0), gloo for the three tiny collectives: exercises the N > 1 path with real kernels "
+                         "on a one-GPU box (tests); not a scaling measurement, and the line says so")
+    ap.add_argument("--verify", action="store_true", help="add the SHA-256 of every rank's first raster to the line (tests compare it with the oracle)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / sharding / reporting path only: gloo, no GPU, no kernel (CPU test of the N > 1 path)")
     ap.add_argument("--prewarm-ms", type=float, default=1500.0,
@@ -289,10 +500,9 @@ def main():
 
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:
-        if not args.dry_run:
-            import torch     # device_count() does not initialise the GPU
-            n = torch.cuda.device_count()
-            if n < args.gpus:
+        if not args.dry_run and not args.share_device:
+            n = visible_gpu_count()          # no HIP call in the parent of the ranks
+            if n is not None and n < args.gpus:
                 raise SystemExit(f"--gpus {args.gpus} but only {n} GPU(s) visible")
         raise SystemExit(spawn_ranks(args))
 
@@ -310,6 +520,11 @@ def main():
     if args.dry_run:
         if world > 1:
             dist.init_process_group("gloo")
+    elif args.share_device:
+        local_rank = 0
+        torch.cuda.set_device(0)
+        if world > 1:
+            dist.init_process_group("gloo")
     else:
         if torch.cuda.device_count() <= local_rank:
             raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but {torch.cuda.device_count()} GPU(s) visible")
@@ -322,113 +537,16 @@ def main():
     if not args.dry_run:
         jg.init(local_rank)
 
-    desc_text, w, h, samp, nf_default = WORKLOADS[args.workload]
-    nf = args.frames or nf_default
-    d = jg.make_desc(w, h, samp)              # host-only geometry
-    full_rows = d.nbmcuV
-    qt = synth.shaun_qtables()
-
-    # ---- what this rank does in one step -------------------------------------------------------------
-    # launches: list of frame counts; every launch works on its own buffers
+    m = measure(jg, args.workload, args.frames, args.steps, args.warmup, args.prewarm_ms, args.scaling == "strong", args.images,
+                rank, world, args.dry_run, host_collectives=args.share_device, verify=args.verify)
+    desc_text, w, h, samp, nf, d = m["desc_text"], m["w"], m["h"], m["samp"], m["nf"], m["desc"]
+    launches, kernel_ms, t_max, per_rank_us = m["launches"], m["kernel_ms"], m["t_max"], m["per_rank_us"]
+    total_pixels_per_step, shard_text, nb, frames_resident, bytes_per_frame = m["total_pixels_per_step"], m["shard_text"], m["nb"], m["frames_resident"], m["bytes_per_frame"]
     strong = args.scaling == "strong"
-    if strong and args.workload == "c5":
-        my_images = sharding.shard_images(args.images, rank, world)           # image i -> rank i mod N
-        launches = [min(nf, len(my_images) - i) for i in range(0, len(my_images), nf)]
-        total_pixels_per_step = args.images * w * h                            # whole job, all ranks
-        shard_text = f"strong: {args.images} independent images, image i on rank i mod {world}, {len(my_images)} on this rank in launches of {nf}; no collective"
-    elif strong:
-        m0, m1 = sharding.shard_mcu_rows(full_rows, rank, world)               # MCU-row stripe of every frame
-        d.nbmcuV = m1 - m0
-        launches = [nf] if m1 > m0 else []
-        total_pixels_per_step = nf * w * h
-        shard_text = f"strong: {nf} frames per step cut into MCU-row stripes, rank g decodes rows [g*{full_rows}/{world}, (g+1)*{full_rows}/{world}); no collective"
-    else:
-        launches = [nf]
-        total_pixels_per_step = world * nf * w * h
-        shard_text = "weak: independent images per rank, no collective"
-    nb = [jg.plane_blocks(d, c) for c in range(d.nbcomp)]
-    rows, rb = jg.raster_rows(d), jg.raster_row_bytes(d)
-    frames_resident = sum(launches)
-    bytes_per_frame = algorithmic_bytes(jg, d)
-
-    kernel_ms, t_local = [], 0.0
-    if args.dry_run:
-        t_local = 1e-3 * args.steps * max(1, len(launches))
-        kernel_ms = [1.0] * (args.steps * max(1, len(launches)))
-    elif launches:
-        # distinct synthetic frames; beyond KMAX the buffers repeat frame f mod KMAX (replicated on the device: generating
-        # 51 GB of coefficients on the host would take minutes) -- every frame still has its own memory
-        KMAX = 32
-        kdist = min(frames_resident, KMAX)
-        planes = []
-        for c in range(d.nbcomp):
-            host = np.empty((kdist * nb[c], 64), dtype=np.int16)
-            for f in range(kdist):
-                host[f * nb[c]:(f + 1) * nb[c]] = synth.synth_blocks(nb[c], 0x5EED0000 + c, (rank * frames_resident + f) * nb[c], 0)
-            t = torch.from_numpy(host).cuda()
-            if frames_resident > kdist:
-                t = t.repeat((frames_resident + kdist - 1) // kdist, 1)[:frames_resident * nb[c]].contiguous()
-            planes.append(t)
-        out = torch.empty(frames_resident * rows * rb, dtype=torch.uint8, device="cuda")
-        stream = torch.cuda.Stream()      # a real (non-NULL) HIP stream: kernels AND events go on it
-        firsts = [sum(launches[:i]) for i in range(len(launches))]
-
-        def launch(i):
-            f0 = firsts[i]
-            jg.backend_run_batch_device(d, launches[i], [planes[c].data_ptr() + f0 * nb[c] * 128 for c in range(d.nbcomp)], None, qt,
-                                        out.data_ptr() + f0 * rows * rb, 0, 0, stream.cuda_stream)
-
-        def step():
-            for i in range(len(launches)):
-                launch(i)
-
-        def fence():
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-
-        t_pre = time.perf_counter()
-        while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
-            for _ in range(max(1, 20 // len(launches))):
-                step()
-            torch.cuda.synchronize()
-        for _ in range(args.warmup):
-            step()
-        fence()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps * len(launches))]
-        t0 = time.perf_counter()
-        k = 0
-        for _ in range(args.steps):
-            for i in range(len(launches)):
-                a, b = ev[k]
-                k += 1
-                a.record(stream)
-                launch(i)
-                b.record(stream)
-        torch.cuda.synchronize()
-        t_local = time.perf_counter() - t0
-        fence()
-        kernel_ms = [a.elapsed_time(b) for a, b in ev]
-    if world > 1:
-        dev = "cpu" if args.dry_run else "cuda"
-        tt = torch.tensor([t_local], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t_max = float(tt.item())
-        mine = torch.tensor([float(np.mean(kernel_ms)) * 1e3 if kernel_ms else 0.0], dtype=torch.float64, device=dev)
-        per_rank = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(per_rank, mine)
-        per_rank_us = [round(float(x.item()), 2) for x in per_rank]
-    else:
-        t_max = t_local
-        per_rank_us = [round(float(np.mean(kernel_ms)) * 1e3, 2)]
-
+    qt = m["qt"]
     value = total_pixels_per_step * args.steps / t_max / 1e6
     # roofline of the dominant kernel: full-size launches of this rank
-    full = [ms for j, ms in enumerate(kernel_ms) if launches and launches[j % len(launches)] == max(launches)]
-    launch_s = float(np.mean(full)) / 1e3 if full else float("nan")
-    bytes_per_launch = (max(launches) if launches else 0) * bytes_per_frame
-    achieved = bytes_per_launch / launch_s / 1e9 if full else 0.0
+    full, launch_s, bytes_per_launch, achieved = roofline_of(m)
     traffic, traffic_source = None, None
     tf = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-measured HBM bytes per launch, if collected
     if os.path.exists(tf) and not strong:
@@ -443,7 +561,7 @@ def main():
         "metric": "MPix/s IQZZ+IDCT+upsample+YCbCr->RGB", "value": round(value, 1), "unit": "MPix/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(t_max / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32+i32 (u8 out)",
-        "data": "synthetic" + (" (frames beyond 32 per rank repeat frame f mod 32, each in its own memory)" if frames_resident > 32 else ""),
+        "data": "synthetic" + (" (frames beyond 512 per rank repeat frame f mod 512, each in its own memory)" if frames_resident > 512 else ""),
         "config": {"workload": f"{args.workload}: {desc_text}", "frames_per_launch": nf, "launches_per_step_rank0": len(launches),
                    "width": w, "height": h, "sampling": [list(s) for s in samp], "blocks_per_frame_rank0": int(sum(nb)), "sharding": shard_text},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -453,6 +571,10 @@ def main():
     }
     if args.dry_run:
         res["dry_run"] = True
+    if args.verify:
+        res["first_raster_sha256"] = m["first_raster_sha256"]
+    if args.share_device:
+        res["share_device"] = f"all {world} ranks on device 0 (gloo for the collectives): a test of the N > 1 path, not a scaling measurement"
     if os.environ.get("JPEGGPU_BENCH_TRACE") and rank == 0:
         print("launch_us:", " ".join(f"{x * 1e3:.0f}" for x in kernel_ms), file=sys.stderr)
     if rank == 0 and not args.dry_run:
@@ -477,6 +599,11 @@ def main():
             res["roofline"]["box_torch_copy_GBps"] = None
     if rank == 0:
         solo = world == 1 and not args.dry_run
+        if solo and not args.no_other_workloads and args.workload == "c2" and not strong:
+            try:      # reported next to the headline, never part of it
+                res["roofline"]["other_workloads"] = other_workloads(jg)
+            except Exception as e:      # noqa: BLE001
+                res["roofline"]["other_workloads"] = {"error": repr(e)}
         res["cpu_baseline"] = cpu_baseline(args.workload, w, h, samp, qt) if solo and not args.no_cpu_baseline else None
         if solo and not args.no_end_to_end:
             try:

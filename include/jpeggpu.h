@@ -143,7 +143,7 @@ size_t jpeggpu_raster_row_bytes(const jpeggpu_frame_desc_t *desc);
  * Host-pointer form, synchronous: the frame is cut into stripes of whole MCU rows; all uploads run back to back
  * on one stream, each stripe's kernel and download follow on a second, so that the upload of one stripe, the
  * kernel of the previous and the download of the one before overlap on the full-duplex link (pinned
- * hipMemcpyAsync both ways; see jpeggpu_host_alloc / jpeggpu_host_register below).  With pageable planes or a
+ * hipMemcpyAsync both ways; see jpeggpu_host_alloc below).  With pageable planes or a
  * pageable raster of 16 MiB and more the call starts a helper thread for that direction's staging copies and
  * joins it before it returns.                                                                              */
 int jpeggpu_backend_run(const jpeggpu_frame_desc_t *desc,
@@ -237,17 +237,16 @@ int jpeggpu_backend_run_noalloc(jpeggpu_ctx_t *ctx, const jpeggpu_frame_desc_t *
                                 uint8_t *out, size_t out_stride);
 
 /* Pinned host memory.  jpeggpu_backend_run moves planes and rasters that are pinned -- allocated by
- * jpeggpu_host_alloc / hipHostMalloc, or registered in place by jpeggpu_host_register / hipHostRegister --
- * with the DMA engines directly; pageable memory (what the reference's calloc gives,
+ * jpeggpu_host_alloc / hipHostMalloc (or pinned in place by the caller's own hipHostRegister, where the driver
+ * supports user pointers) -- with the DMA engines directly; pageable memory (what the reference's calloc gives,
  * src/progressive.c:73-84) goes through pinned stripe buffers, one extra copy each way.  A binding that
  * lays `sortie` out contiguously allocates it with jpeggpu_host_alloc instead of calloc.
- * In-place registration needs driver support for user pointers (it is refused with JPEGGPU_ERR_HIP on
- * hosts without it) and costs about as much as a copy: register once per buffer, not per call.
+ * The WHOLE range a call touches has to be pinned for the in-place path: the library probes the first and
+ * the last byte of every plane and raster it is handed (of every frame of a batch, or an even sample of 256
+ * of them) and stages the call through its own buffers otherwise.
  * No counterpart in the reference.                                                                      */
 void *jpeggpu_host_alloc(size_t bytes);          /* NULL on failure (jpeggpu_last_error() says why); not zeroed */
 void  jpeggpu_host_free(void *ptr);
-int   jpeggpu_host_register(void *ptr, size_t bytes);
-int   jpeggpu_host_unregister(void *ptr);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Stage-level array forms of the four function contracts (host pointers, synchronous).        */

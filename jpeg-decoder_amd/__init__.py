@@ -9,6 +9,6 @@ from .backend import (  # noqa: F401
     backend_run, backend_run_batch, backend_run_device, backend_run_batch_device,
     iquant_blocks, izz_blocks, idct_opt_blocks, ycc2rgb_pixels,
     idct_blocks, idct_coef_table, set_idct_fast, get_idct_fast,
-    Context, multi_backend_run, multi_backend_run_batch, reload_tuning, host_register, host_unregister, PinnedArray,
+    Context, multi_backend_run, multi_backend_run_batch, reload_tuning, PinnedArray,
     SUCCESS, ERR_NB_COMP, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_SAMPLING, ERR_NO_QT,
 )

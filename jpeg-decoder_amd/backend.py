@@ -107,8 +107,6 @@ lib.jpeggpu_host_alloc.argtypes = [_sz]
 lib.jpeggpu_host_alloc.restype = _vp
 lib.jpeggpu_host_free.argtypes = [_vp]
 lib.jpeggpu_host_free.restype = None
-lib.jpeggpu_host_register.argtypes = [_vp, _sz]
-lib.jpeggpu_host_unregister.argtypes = [_vp]
 lib.jpeggpu_internal_reload_tuning.restype = None
 
 
@@ -194,15 +192,6 @@ class PinnedArray:
             self.array = None
             lib.jpeggpu_host_free(self.ptr)
             self.ptr = None
-
-
-def host_register(arr):
-    """jpeggpu_host_register on a numpy array's memory (pinned in place until host_unregister)."""
-    _check(lib.jpeggpu_host_register(arr.ctypes.data, arr.nbytes))
-
-
-def host_unregister(arr):
-    _check(lib.jpeggpu_host_unregister(arr.ctypes.data))
 
 
 def backend_run(desc, coef, qtables, out=None, out_stride=0, ctx=None):

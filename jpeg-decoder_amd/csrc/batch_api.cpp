@@ -26,6 +26,7 @@
 extern "C" void jpeggpu_internal_set_error(const char *msg);
 extern "C" int jpeggpu_internal_ensure_init(void);
 extern "C" int jpeggpu_internal_device(void);
+extern "C" int jpeggpu_internal_range_pinned(const void *p, size_t bytes);   // capi.cpp: first and last byte are pinned host memory
 extern "C" void *jpeggpu_internal_pool_take(int host, size_t bytes, int device);   // decode_api.cpp: buffers kept between calls
 extern "C" void jpeggpu_internal_pool_give(int host, void *p, size_t bytes, int device);
 
@@ -79,12 +80,6 @@ struct Resources {
       }
    }
 };
-
-bool pinned_host(const void *p) {
-   hipPointerAttribute_t a;
-   if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-   return a.type == hipMemoryTypeHost;
-}
 
 bool same_geometry(const jpeggpu_frame_desc_t &a, const jpegfe::Decoder &d) {
    if (a.width != d.width || a.height != d.height || a.nbcomp != d.nbcomp) return false;
@@ -221,7 +216,7 @@ extern "C" int jpeggpu_decode_batch(const jpeggpu_blob_t *jpegs, size_t n, uint8
       }
       // the caller's raster array: already pinned (jpeggpu_host_alloc, hipHostMalloc) -> the downloads land there; else
       // pin it in place; where the driver refuses that, stage
-      if (raster_frame_stride == out_bytes && pinned_host(rasters)) {
+      if (raster_frame_stride == out_bytes && jpeggpu_internal_range_pinned(rasters, n * raster_frame_stride)) {
          registered = true;
       } else if (raster_frame_stride == out_bytes && hipHostRegister(rasters, n * raster_frame_stride, hipHostRegisterDefault) == hipSuccess) {
          R.registered = rasters;

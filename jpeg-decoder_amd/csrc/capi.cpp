@@ -383,6 +383,21 @@ bool is_pinned_host(const void *p) {
    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
    return a.type == hipMemoryTypeHost;
 }
+// [p, p + bytes) is pinned host memory: its first AND its last byte are (a buffer that was pinned or registered only in
+// part must not be handed to the DMA engines in place; include/jpeggpu.h: the WHOLE range a call touches has to be pinned)
+bool range_pinned(const void *p, size_t bytes) {
+   return bytes == 0 || (is_pinned_host(p) && is_pinned_host((const char *)p + bytes - 1));
+}
+// the frames first, first + step, ... (count of them), `bytes` each, `stride` apart: every one of them when they are few,
+// an even sample of 256 of them otherwise (always the first and the last)
+bool frames_pinned(const void *base, size_t stride, size_t bytes, uint32_t first, uint32_t step, uint32_t count) {
+   const uint32_t probes = count < 256 ? count : 256;
+   for (uint32_t i = 0; i < probes; i++) {
+      const uint32_t k = probes > 1 ? (uint32_t)((uint64_t)i * (count - 1) / (probes - 1)) : 0;
+      if (!range_pinned((const char *)base + (size_t)(first + k * step) * stride, bytes)) return false;
+   }
+   return true;
+}
 
 // The host-pointer forms.  Every frame is cut into stripes of whole MCU rows (a stripe is a frame of its own to the
 // kernel: replicate upsampling has no halo, src/decoder_utils.c:72-80); the stripes of all frames of the call form one
@@ -391,7 +406,7 @@ bool is_pinned_host(const void *p) {
 // them; a second stream takes, per unit, the wait for that unit's upload, its kernel and its download.  Upload of unit
 // k+1, kernel of unit k and download of unit k-1 overlap -- across the frames of a batch as well -- and the call costs
 // the upload time plus one unit's kernel and download.  Caller memory that
-// is already pinned (jpeggpu_host_alloc, hipHostMalloc, jpeggpu_host_register) is read and written by the DMA engines
+// is already pinned (jpeggpu_host_alloc, hipHostMalloc, the caller's own hipHostRegister) is read and written by the DMA engines
 // in place; pageable memory (the reference's malloc'ed buffers, src/progressive.c:73-84) goes through two pinned
 // buffers per direction, filled and emptied by host threads while the other unit is in flight.
 //
@@ -420,11 +435,10 @@ int run_host(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, uint32_t first, 
       in_per_mcu_row += row_in[c];
    }
    const size_t band = (size_t)d->max_v * 8;                 // raster rows per MCU row
-   const uint32_t last = first + (count - 1) * step;
    bool in_pinned = true;
    for (int c = 0; c < d->nbcomp; c++)
-      in_pinned = in_pinned && is_pinned_host((const char *)coef[c] + (size_t)first * fstride[c]) && is_pinned_host((const char *)coef[c] + (size_t)last * fstride[c]);
-   const bool out_pinned = is_pinned_host(out + (size_t)first * out_frame_stride) && is_pinned_host(out + (size_t)last * out_frame_stride);
+      in_pinned = in_pinned && frames_pinned(coef[c], fstride[c], jpeggpu_plane_blocks(d, c) * sizeof(jpeggpu_blocl16_t), first, step, count);
+   const bool out_pinned = frames_pinned(out, out_frame_stride, (rows - 1) * out_stride + row_bytes, first, step, count);
    // stripe height: ~16 MiB of coefficients when the DMA engines work in place, ~8 MiB when a host thread stages
    // (tools/sweep_stripe.py, profiles/r02_sweep_stripe.txt), at least one MCU row, at most the frame
    const size_t target = tuning().stripe_bytes ? tuning().stripe_bytes : ((size_t)(in_pinned && out_pinned ? 16 : 8) << 20);
@@ -611,6 +625,7 @@ extern "C" {
 const char *jpeggpu_last_error(void) { return g_err; }
 
 // used by decode_api.cpp / batch_api.cpp (same library); not part of the public headers
+int jpeggpu_internal_range_pinned(const void *p, size_t bytes) { return range_pinned(p, bytes) ? 1 : 0; }   // batch_api.cpp, decode_api.cpp
 void jpeggpu_internal_set_error(const char *msg) { snprintf(g_err, sizeof g_err, "%s", msg ? msg : ""); }
 int jpeggpu_internal_ensure_init(void) { jpeggpu_ctx_s *c; return default_ctx(&c); }   // also binds the calling thread to the device
 int jpeggpu_internal_device(void) { jpeggpu_ctx_s *c = g_default.load(); return c ? c->device : 0; }
@@ -840,6 +855,10 @@ int jpeggpu_backend_run_noalloc(jpeggpu_ctx_t *ctx, const jpeggpu_frame_desc_t *
                   in_bytes + out_bytes, in_bytes, out_bytes, (size_t)kStaticScratchBytes);
    uint8_t *base = (uint8_t *)ctx->static_scratch;     // the DEVICE address, never the array's name
    std::lock_guard<std::mutex> lk(device_mu[ctx->device]);
+   // Whatever way this section is left, nothing of it may still be queued when the mutex goes: the next caller on this GPU
+   // overwrites the shared array, and the caller's planes and raster must not be touched after the return.  (Declared
+   // after the lock: destroyed before it.)
+   struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{ ctx->stream };
    const void *dc[3] = { nullptr, nullptr, nullptr };
    for (int c = 0; c < d->nbcomp; c++) {
       HIP_TRY(hipMemcpyAsync(base + off[c], coef[c], jpeggpu_plane_blocks(d, c) * sizeof(jpeggpu_blocl16_t), hipMemcpyHostToDevice, ctx->stream));
@@ -847,7 +866,7 @@ int jpeggpu_backend_run_noalloc(jpeggpu_ctx_t *ctx, const jpeggpu_frame_desc_t *
    }
    uint8_t *d_raster = base + in_bytes;
    rc = run_device(ctx, d, 1, dc, nullptr, qt, d_raster, row_bytes, 0, ctx->stream, false);
-   if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+   if (rc) return rc;
    if (out_stride == row_bytes) HIP_TRY(hipMemcpyAsync(out, d_raster, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
    else HIP_TRY(hipMemcpy2DAsync(out, out_stride, d_raster, row_bytes, row_bytes, rows, hipMemcpyDeviceToHost, ctx->stream));
    HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -863,19 +882,6 @@ void *jpeggpu_host_alloc(size_t bytes) {
    return p;
 }
 void jpeggpu_host_free(void *ptr) { if (ptr) (void)hipHostFree(ptr); }
-
-// Pins caller memory in place (where the driver supports it) to the same effect.
-int jpeggpu_host_register(void *ptr, size_t bytes) {
-   if (!ptr || !bytes) return fail(JPEGGPU_ERR_INVALID_ARG, "NULL argument");
-   jpeggpu_ctx_s *c; int rc = default_ctx(&c); if (rc) return rc;
-   HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
-   return 0;
-}
-int jpeggpu_host_unregister(void *ptr) {
-   if (!ptr) return fail(JPEGGPU_ERR_INVALID_ARG, "NULL argument");
-   HIP_TRY(hipHostUnregister(ptr));
-   return 0;
-}
 
 // ---- stage-level array forms -----------------------------------------------------------------
 

@@ -46,6 +46,7 @@ int dfail(int code, const char *fmt, ...) {
 // capi.cpp: lets this file report through jpeggpu_last_error()
 extern "C" void jpeggpu_internal_set_error(const char *msg);
 extern "C" int jpeggpu_internal_ensure_init(void);
+extern "C" int jpeggpu_internal_range_pinned(const void *p, size_t bytes);   // capi.cpp: first and last byte are pinned host memory
 extern "C" size_t jpeggpu_internal_stripe_bytes(void);
 
 struct jpeggpu_jpeg {
@@ -551,9 +552,7 @@ int jpeggpu_jpeg_render(jpeggpu_jpeg_t *j, uint8_t *out, size_t out_stride) {
    const size_t rb = jpeggpu_raster_row_bytes(&desc), rows = jpeggpu_raster_rows(&desc);
    if (out_stride == 0) out_stride = rb;
    if (out_stride < rb) { jpeggpu_internal_set_error("out_stride plus petit qu'une ligne"); return JPEGGPU_ERR_INVALID_ARG; }
-   hipPointerAttribute_t pa;
-   const bool direct = j->pinned && rb * rows != 0 && hipPointerGetAttributes(&pa, out) == hipSuccess && pa.type == hipMemoryTypeHost;
-   if (!direct) (void)hipGetLastError();
+   const bool direct = j->pinned && rb * rows != 0 && jpeggpu_internal_range_pinned(out, (rows - 1) * out_stride + rb);
    int rc = render_begin(j, direct ? out : nullptr, out_stride);
    if (rc) return rc;
    rc = render_end(j);

@@ -7,7 +7,15 @@
 #include <cstdio>
 #include <cstring>
 
+#include "../../include/jpeggpu.h"
 #include "../../include/jpeggpu_decode.h"
+
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define JPEG2PPM_ASAN 1
+extern "C" void __sanitizer_purge_allocator(void);
+#endif
+#endif
 
 static int usage(const char *exe, int code, const char *why) {
    if (why) fprintf(stderr, "Erreur %d : %s\n", code, why);
@@ -15,7 +23,25 @@ static int usage(const char *exe, int code, const char *why) {
    return code;
 }
 
+static int run(int argc, char **argv);
+
+// Everything the library holds on the GPU (default context, streams, events, the "-f" table, the pools of pinned and
+// device buffers kept between files) is given back BEFORE main returns, not left to static destruction after it: the HIP
+// and HSA runtimes tear themselves down from their own finalisers, in an order this program does not control.
 int main(int argc, char **argv) {
+   const int rc = run(argc, argv);
+   jpeggpu_shutdown();
+#if defined(JPEG2PPM_ASAN)
+   // Host-ASan builds (tools/asan_cli.sh): ROCm's AddressSanitizer runtime keeps freed HSA allocations (pinned and device
+   // buffers: it wraps hsa_amd_memory_pool_allocate) in its quarantine and gives them back to HSA when the quarantine is
+   // recycled -- if that happens inside the runtimes' finalisers, after HSA has shut down, it aborts with "CHECK failed:
+   // sanitizer_allocator_device.h ... dev_runtime_unloaded_".  Drain the quarantine now, while the runtime is alive.
+   __sanitizer_purge_allocator();
+#endif
+   return rc;
+}
+
+static int run(int argc, char **argv) {
    const char *in = nullptr, *out = nullptr;
    bool timer = false;
    for (int i = 1; i < argc; i++) {

@@ -62,3 +62,50 @@ SHAUN_QT_CHROMA = np.array([11, 11, 11, 15, 13, 15, 29, 16, 16, 29, 61, 41, 35, 
 
 def shaun_qtables():
     return [SHAUN_QT_LUMA, SHAUN_QT_CHROMA, None, None]
+
+
+# ---- the same generator on a torch device (bench.py: gigabytes of coefficients without minutes of numpy) -------------
+def _lsr(x, n):
+    """logical right shift of an int64 tensor holding a uint64 bit pattern"""
+    return (x >> n) & ((1 << (64 - n)) - 1)
+
+
+def _splitmix64_t(x):
+    x = x + (0x9E3779B97F4A7C15 - (1 << 64))           # int64 arithmetic wraps like uint64
+    x = (x ^ _lsr(x, 30)) * (0xBF58476D1CE4E5B9 - (1 << 64))
+    x = (x ^ _lsr(x, 27)) * (0x94D049BB133111EB - (1 << 64))
+    return x ^ _lsr(x, 31)
+
+
+def synth_blocks_torch(n, seed, first_block=0, kind=0, device="cuda", chunk=1 << 20):
+    """synth_blocks() computed on `device`: an (n, 64) int16 tensor with the same bytes (tests/test_synth.py)."""
+    import torch
+    out = torch.empty((n, 64), dtype=torch.int16, device=device)
+    k = torch.arange(64, dtype=torch.int64, device=device)[None, :]
+    base = (int(seed) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    if base >= 1 << 63:
+        base -= 1 << 64
+    pz = torch.clamp((torch.arange(64, dtype=torch.int64, device=device) * 256) // 48, max=243)[None, :]
+    scale = (4259 // (1 + torch.arange(64, dtype=torch.int64, device=device)))[None, :]
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        gb = (torch.arange(s, e, dtype=torch.int64, device=device) + int(first_block))[:, None]
+        h = _splitmix64_t(base + gb * 64 + k)
+        if kind == 2:
+            v = (h & 0xFFFF).to(torch.int64)
+            v = torch.where(v >= 0x8000, v - 0x10000, v)
+        elif kind == 1:
+            hi, lo = _lsr(h, 32), h & 0xFFFFFFFF
+            v = ((hi % 2049) * ((1 << 32) % 2049) + lo % 2049) % 2049 - 1024
+        else:
+            u = _lsr(h, 32) | 1
+            g = 32 - torch.frexp(u.to(torch.float64))[1].to(torch.int64)      # leading zeros of the 32-bit value
+            frac = _lsr(h, 8) & 0xFF
+            mag = (((g * 256 + frac) * scale) & 0xFFFFFFFF) >> 16
+            v = torch.where((h & (1 << 16)) != 0, -mag, mag)
+            v = torch.where((h & 0xFF) < pz, torch.zeros_like(v), v)
+            h0 = h[:, 0]
+            hi, lo = _lsr(h0, 32), h0 & 0xFFFFFFFF
+            v[:, 0] = ((hi % 129) * ((1 << 32) % 129) + lo % 129) % 129 - 64
+        out[s:e] = v.to(torch.int16)
+    return out

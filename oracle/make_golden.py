@@ -32,6 +32,27 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+def kat_frames(meta, blocks):
+    meta["kat_frames"] = {}
+    for layout in ("gray", "444", "420"):
+        for (aq, idq, tag) in ((1, [0, 0, 0], "ramp"), (1, [2, 2, 2], "wrap"), (0, [0, 1, 1], "noq")):
+            samp, w, h, planes = helpers.kat_frame(blocks, layout)
+            d = helpers.oracle_desc(w, h, samp, idq=idq[:len(samp)], apply_iquant=bool(aq))
+            assert all(planes[c].shape == helpers.plane_shape(d, c) for c in range(len(samp)))
+            out = ref.backend_run(d, planes, qt)
+            meta["kat_frames"][f"{layout}_{tag}"] = {"layout": layout, "apply_iquant": aq, "idq": idq, "rows": int(out.shape[0]), "sha256": sha(out)}
+
+
+if "--kat-only" in sys.argv:      # adds meta.json["kat_frames"] from the committed stage vectors, leaves everything else alone
+    mp = os.path.join(OUT, "meta.json")
+    meta = json.load(open(mp))
+    kat_frames(meta, np.load(os.path.join(OUT, "stage_vectors.npz"))["blocks"])
+    with open(mp, "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print("kat_frames:", {k: v["sha256"][:12] for k, v in meta["kat_frames"].items()})
+    sys.exit(0)
+
+
 # ---- stage-level vectors --------------------------------------------------------------------
 imp = np.zeros((64 * 6, 64), dtype=np.int16)
 for k in range(64):
@@ -57,6 +78,7 @@ allrgb = ref.ycc2rgb_pixels(y, cb, cr)
 pick = np.concatenate([np.arange(0, 1 << 24, 4099), ((228 << 16) | (28 << 8)) + np.arange(256)])  # incl. the y-dependent pair
 np.savez_compressed(os.path.join(OUT, "ycc2rgb_vectors.npz"), index=pick.astype(np.uint32), rgb=allrgb[pick])
 meta = {"ycc2rgb_all_sha256": sha(allrgb), "frames": {}}
+kat_frames(meta, blocks)
 
 # ---- frame-level vectors: small rasters raw, larger ones as hashes ---------------------------
 combos = {"gray": ((1, 1),), "444": ((1, 1),) * 3, "422": ((2, 1), (1, 1), (1, 1)), "420": ((2, 2), (1, 1), (1, 1)),

@@ -52,3 +52,19 @@ def sha256_hex(a):
     """SHA-256 of an array's bytes (the digest the golden metadata stores)."""
     import hashlib
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def kat_frame(blocks, layout):
+    """(desc sampling, width, height, planes) of the frame that carries the adversarial stage blocks (impulses at each of
+    the 64 positions x +-{1, 1024, 2047}, all-32767 / all--32768, synthetic kinds 0-2) through the FUSED path: 640 blocks
+    per chroma-sized plane (the 612 vectors + zero blocks), 64 x 10 MCUs, so that 4:4:4 takes whole 64-MCU tiles and 4:2:0
+    whole 32-MCU tiles.  Cb / Cr = the same blocks rotated by 211 / 422 places, Y of 4:2:0 = four rotations."""
+    b = np.concatenate([blocks, np.zeros((640 - blocks.shape[0], 64), np.int16)])
+    if layout == "gray":
+        return ((1, 1),), 512, 80, [b]
+    if layout == "444":
+        return ((1, 1),) * 3, 512, 80, [b, np.roll(b, 211, 0), np.roll(b, 422, 0)]
+    if layout == "420":
+        y = np.concatenate([b, np.roll(b, 101, 0), np.roll(b, 307, 0), np.roll(b, 499, 0)])
+        return ((2, 2), (1, 1), (1, 1)), 1024, 160, [y, np.roll(b, 211, 0), np.roll(b, 422, 0)]
+    raise ValueError(layout)

@@ -209,6 +209,32 @@ def test_linear_tiling(gpu, samp):
         assert np.array_equal(outs[0][f], orc.backend_run(d, [host[c][f * nb[c]:(f + 1) * nb[c]] for c in range(3)], QT)), f
 
 
+@pytest.mark.parametrize("knob", [None, "JPEGGPU_NO_RESTAGE", "JPEGGPU_NO_UNIFORM"], ids=["default", "no_restage", "per_lane_prologue"])
+def test_kat_frames_through_the_fused_kernels(gpu, knob):
+    """SURVEY 8d's adversarial set -- impulses at each of the 64 positions x +-{1, 1024, 2047}, all-32767 / all--32768 blocks,
+    full-range int16 under the wrapping table (test/iqzz_test.c:21-29,48-64 are the reference's own KATs for the two stages) --
+    through jpeggpu_backend_run, i.e. through izz_rp + idct_block_rp with their packed op_sel/neg instructions (the stage
+    entry jpeggpu_idct_opt_blocks runs the scalar idct_block instead): gray, 4:4:4 (backend_kernel_rs444) and 4:2:0
+    (backend_kernel_rs420) frames, each also through the general kernel and its per-lane prologue.  Against the oracle byte
+    for byte and against the hash of the compiled reference (tests/golden/meta.json, oracle/make_golden.py --kat-only)."""
+    meta = json.load(open(os.path.join(G, "meta.json")))["kat_frames"]
+    blocks = np.load(os.path.join(G, "stage_vectors.npz"))["blocks"]
+    if knob:
+        os.environ[knob] = "1"
+    gpu.reload_tuning()
+    try:
+        for key, info in sorted(meta.items()):
+            samp, w, h, planes = helpers.kat_frame(blocks, info["layout"])
+            d = helpers.oracle_desc(w, h, samp, idq=info["idq"][:len(samp)], apply_iquant=bool(info["apply_iquant"]))
+            got = gpu.backend_run(helpers.to_gpu_desc(gpu, d), planes, QT)
+            assert got.shape[0] == info["rows"] and sha(got) == info["sha256"], key
+            assert np.array_equal(got, orc.backend_run(d, planes, QT)), key
+    finally:
+        if knob:
+            os.environ.pop(knob, None)
+        gpu.reload_tuning()
+
+
 RS_CASES = {
     # (width, height, frames, row padding, apply_iquant)
     "444": (((1, 1),) * 3, [(512, 8, 1, 0, True), (1024, 24, 3, 16, False), (1536, 13, 2, 48, True), (2048, 40, 1, 7, True), (4096, 16, 2, 0, False)]),

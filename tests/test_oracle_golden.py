@@ -150,3 +150,18 @@ def test_oracle_whole_rasters_at_baseline_sizes(name):
     assert hashlib.sha256(np.ascontiguousarray(out[:band]).tobytes()).hexdigest() == gold["sha256_first_band"]
     assert hashlib.sha256(np.ascontiguousarray(out[-band:]).tobytes()).hexdigest() == gold["sha256_last_band"]
     assert hashlib.sha256(out.tobytes()).hexdigest() == gold["sha256"]
+
+
+def test_kat_frames_through_the_oracle():
+    """The adversarial stage blocks (64 impulse positions x +-{1, 1024, 2047}, all-32767, all--32768, full-range int16) as
+    whole gray / 4:4:4 / 4:2:0 frames, with the ramp table, the int16-wrapping table and without iquant: oracle raster ==
+    the hash the compiled reference produced (oracle/make_golden.py --kat-only)."""
+    import json
+    meta = json.load(open(os.path.join(helpers.GOLDEN, "meta.json")))["kat_frames"]
+    blocks = np.load(os.path.join(helpers.GOLDEN, "stage_vectors.npz"))["blocks"]
+    assert len(meta) == 9
+    for key, info in sorted(meta.items()):
+        samp, w, h, planes = helpers.kat_frame(blocks, info["layout"])
+        d = helpers.oracle_desc(w, h, samp, idq=info["idq"][:len(samp)], apply_iquant=bool(info["apply_iquant"]))
+        out = pyoracle.oracle.backend_run(d, planes, helpers.qtables_ramp())
+        assert out.shape[0] == info["rows"] and helpers.sha256_hex(out) == info["sha256"], key

@@ -26,3 +26,15 @@ def test_bench_qtables_are_shauns():
     z = np.load(os.path.join(helpers.GOLDEN, "shaun_the_sheep_planes.npz"))
     q = synth.shaun_qtables()
     assert np.array_equal(q[0], z["qtables"][0]) and np.array_equal(q[1], z["qtables"][1]) and q[2] is None
+
+
+def test_torch_generator_gives_the_same_bytes():
+    """bench.py fills its device buffers with synth.synth_blocks_torch: same bytes as the numpy generator (and hence as the
+    oracle's C generator), for every kind, across chunk boundaries and with large block offsets."""
+    import numpy as np
+    from jpeg_decoder_amd import synth
+    for kind in (0, 1, 2):
+        for seed, fb in ((0x5EED0000, 0), (0x5EED0002, 123456789012), (7, 5)):
+            a = synth.synth_blocks(3000, seed, fb, kind)
+            b = synth.synth_blocks_torch(3000, seed, fb, kind, device="cpu", chunk=1777).numpy()
+            assert np.array_equal(a, b), (kind, seed, fb)

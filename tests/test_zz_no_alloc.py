@@ -7,9 +7,11 @@ import numpy as np
 import pytest
 
 import helpers
+from oracle import pyoracle
 
 pytestmark = pytest.mark.gpu
 QT = helpers.qtables_ramp()
+orc = pyoracle.oracle
 
 
 def _call_noalloc(gpu, gd, planes, qts, out, out_stride=0, ctx=None):
@@ -31,7 +33,8 @@ def test_noalloc_entry_equals_backend_run_twice_in_a_row(gpu):
         d = helpers.oracle_desc(w, h, samp)
         planes = helpers.synth_planes(d, seed)
         gd = helpers.to_gpu_desc(gpu, d)
-        want = gpu.backend_run(gd, planes, QT)                       # the existing entry point (itself pinned to the oracle)
+        want = gpu.backend_run(gd, planes, QT)                       # the existing entry point
+        assert np.array_equal(want, orc.backend_run(d, planes, QT)), (w, h, samp)      # ... and the oracle, directly
         got = np.full_like(want, 0x5A)
         rc = _call_noalloc(gpu, gd, planes, QT, got)
         assert rc == 0, gpu.last_error()
@@ -58,3 +61,42 @@ def test_noalloc_entry_on_a_context_and_its_limit(gpu):
     out = np.zeros(16, np.uint8)
     rc = _call_noalloc(gpu, big, [one, one, one], QT, out)
     assert rc == gpu.ERR_INVALID_ARG and "static buffer" in gpu.last_error()
+
+
+def test_noalloc_entry_leaves_device_and_pinned_memory_alone(gpu):
+    """The entry's defining property: no hipMalloc / hipHostMalloc behind it.  Free device memory (hipMemGetInfo) is the same
+    before and after two calls in a row; also with idct_fast == 0 once its table is on the device; results equal the oracle."""
+    import torch
+    d = helpers.oracle_desc(640, 360, ((2, 2), (1, 1), (1, 1)))
+    planes = helpers.synth_planes(d, 75)
+    gd = helpers.to_gpu_desc(gpu, d)
+    want = orc.backend_run(d, planes, QT)
+    got = np.zeros_like(want)
+    assert _call_noalloc(gpu, gd, planes, QT, got) == 0, gpu.last_error()       # everything lazy (code object, streams) is set up now
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for (w, h) in ((640, 360), (200, 100)):
+        d2 = helpers.oracle_desc(w, h, ((2, 2), (1, 1), (1, 1)))
+        p2 = helpers.synth_planes(d2, 76 + w)
+        o2 = np.zeros_like(orc.backend_run(d2, p2, QT))
+        assert _call_noalloc(gpu, helpers.to_gpu_desc(gpu, d2), p2, QT, o2) == 0, gpu.last_error()
+        assert np.array_equal(o2, orc.backend_run(d2, p2, QT)), (w, h)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 == free0, (free0, free1)
+    # "-f": the direct transform needs its table on the device; an ordinary call puts it there, then the entry may run
+    gpu.set_idct_fast(False)
+    try:
+        orc.set_idct_fast(False)
+        want_slow = orc.backend_run(d, planes, QT)
+        assert np.array_equal(gpu.backend_run(gd, planes, QT), want_slow)
+        torch.cuda.synchronize()
+        free2, _ = torch.cuda.mem_get_info()
+        got = np.zeros_like(want)
+        assert _call_noalloc(gpu, gd, planes, QT, got) == 0, gpu.last_error()
+        assert np.array_equal(got, want_slow)
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info()[0] == free2
+    finally:
+        gpu.set_idct_fast(True)
+        orc.set_idct_fast(True)

@@ -88,6 +88,38 @@ template <int M> __global__ void __launch_bounds__(192) k(const u32x4 *in, uint8
       }
       return;
    }
+   if (M == 12) {   // M9 balanced: every wave one whole unit + one of the three stores of unit 3 (only a data-free benchmark can do that)
+      const uint32_t o[3] = { lane * 16, lane < 32 ? 1024 + lane * 16 : (uint32_t)stride + (lane - 32) * 16, (uint32_t)stride + 512 + lane * 16 };
+      uint8_t *ub = tile_out + 2 * wave * stride;
+      __builtin_nontemporal_store(u32x4{w[0][0], w[0][1], w[1][0], w[1][1]}, reinterpret_cast<u32x4 *>(ub + o[0]));
+      __builtin_nontemporal_store(u32x4{w[1][0], w[1][1], w[2][0], w[2][1]}, reinterpret_cast<u32x4 *>(ub + o[1]));
+      __builtin_nontemporal_store(u32x4{w[2][0], w[2][1], w[0][0], w[0][1]}, reinterpret_cast<u32x4 *>(ub + o[2]));
+      ub = tile_out + 6 * stride;
+      __builtin_nontemporal_store(u32x4{w[3][0], w[3][1], w[4][0], w[4][1]}, reinterpret_cast<u32x4 *>(ub + (wave == 0 ? o[0] : wave == 1 ? o[1] : o[2])));
+      return;
+   }
+   if (M == 13) {   // M6's geometry (rows of 2048 B per tile, no store spans two rows) with M9's 2/1/1 assignment: unit = 3 runs
+      uint8_t *t2 = out + (wg / 6) * (6 * (size_t)12288) + (wg % 6) * 2048;
+      int k2 = 0;
+      for (uint32_t u = wave; u < 4; u += 3)
+         for (uint32_t r3 = 0; r3 < 3; r3++, k2++) {
+            const uint32_t run = u * 3 + r3, row = run >> 1, half = run & 1;
+            __builtin_nontemporal_store(u32x4{w[k2][0], w[k2][1], w[k2 + 1][0], w[k2 + 1][1]}, reinterpret_cast<u32x4 *>(t2 + row * 12288 + half * 1024 + lane * 16));
+         }
+      return;
+   }
+   if (M == 14) {   // M9 with the units dealt 1/2/1 ... no: M9 with the heavy wave rotating from workgroup to workgroup
+      const uint32_t o0 = lane * 16, o1 = lane < 32 ? 1024 + lane * 16 : (uint32_t)stride + (lane - 32) * 16, o2 = (uint32_t)stride + 512 + lane * 16;
+      const uint32_t wv = (wave + (uint32_t)wg) % 3;
+      int k2 = 0;
+      for (uint32_t u = wv; u < 4; u += 3, k2 += 3) {
+         uint8_t *ub = tile_out + 2 * u * stride;
+         __builtin_nontemporal_store(u32x4{w[k2][0], w[k2][1], w[k2 + 1][0], w[k2 + 1][1]}, reinterpret_cast<u32x4 *>(ub + o0));
+         __builtin_nontemporal_store(u32x4{w[k2 + 1][0], w[k2 + 1][1], w[k2 + 2][0], w[k2 + 2][1]}, reinterpret_cast<u32x4 *>(ub + o1));
+         __builtin_nontemporal_store(u32x4{w[k2 + 2][0], w[k2 + 2][1], w[k2][0], w[k2][1]}, reinterpret_cast<u32x4 *>(ub + o2));
+      }
+      return;
+   }
    if (M == 10 || M == 11) {   // the kernel's skeleton with the wave-private restage: planes interleaved per row pair in LDS
       // (unit u = [Y rows 2u,2u+1 | Cb | Cr] = 3072 contiguous bytes), barrier, then per unit: every lane reads 3 x 16 bytes
       // (16 pixels of each plane), writes 48 bytes of "RGB" back over the unit at 48 * lane, reads 16-byte pieces at
@@ -181,7 +213,9 @@ int main() {
       run<8>("M8 M1, every wave writes whole rows (both halves)", d, o, wgs, 8);
       run<9>("M9 16-byte stores, row-pair units (3 x 1024 B per unit), waves 2/1/1", d, o, wgs, 8);
       run<10>("M10 skeleton with wave-private restage in LDS (M9's stores)", d, o, wgs, 8);
-      run<11>("M11 M10's LDS layout, 12-byte stores (16 px per lane)", d, o, wgs, 8);
+      run<12>("M12 M9 balanced 4/4/4 (unit 3's stores one per wave)", d, o, wgs, 8);
+      run<13>("M13 M6's rows of 2048 B with M9's 2/1/1 units", d, o, wgs / 6 * 6, 6);
+      run<14>("M14 M9, heavy wave rotating with the workgroup", d, o, wgs, 8);
    }
    return 0;
 }
