@@ -26,6 +26,9 @@
 #ifndef JM_WAVES_PER_EU
 #define JM_WAVES_PER_EU 6
 #endif
+#ifndef JM_RS_NT
+#define JM_RS_NT 1         // the 16-byte raster stores of the restage kernels carry the non-temporal hint as well
+#endif
 #ifndef JM_RS_WAVES_PER_EU
 #define JM_RS_WAVES_PER_EU 7   // the 4:4:4 restage kernel fits 72 VGPRs without spills: 7 waves per SIMD = 9 workgroups per CU
 #endif
@@ -43,6 +46,15 @@
 namespace jpeggpu_k {
 
 using namespace jpegmath;
+
+typedef uint32_t rs_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void rs_store16(uint8_t *dst, rs_u32x4 v) {
+#if JM_RS_NT
+   __builtin_nontemporal_store(v, reinterpret_cast<rs_u32x4 *>(dst));
+#else
+   *reinterpret_cast<rs_u32x4 *>(dst) = v;
+#endif
+}
 
 struct __attribute__((packed, aligned(4))) rgb4_t { uint32_t a, b, c; };
 
@@ -264,9 +276,9 @@ __device__ __forceinline__ void pixel_phase_units444(const BackendParams &p, uin
       const u32x4 s1 = *reinterpret_cast<const u32x4 *>(ul + 1024 + l * 16);
       const u32x4 s2 = *reinterpret_cast<const u32x4 *>(ul + 2048 + l * 16);
       uint8_t *ub = tile_out + (size_t)(2 * u) * stride;      // wave-uniform
-      __builtin_nontemporal_store(s0, reinterpret_cast<u32x4 *>(ub + o0));
-      __builtin_nontemporal_store(s1, reinterpret_cast<u32x4 *>(ub + o1));
-      __builtin_nontemporal_store(s2, reinterpret_cast<u32x4 *>(ub + o2));
+      rs_store16(ub + o0, s0);
+      rs_store16(ub + o1, s1);
+      rs_store16(ub + o2, s2);
    }
 }
 
@@ -650,6 +662,16 @@ __global__ void __launch_bounds__(192, JM_R2_WAVES_PER_EU) backend_kernel_rs420(
       m0 = g0 / p.nbmcuH; c0 = g0 - m0 * p.nbmcuH; wrapj = p.nbmcuH - c0; nvalid = min(32u, p.total_mcus - g0);
    } else {
       m0 = blockIdx.y; c0 = blockIdx.x * 32; wrapj = 0x7FFFFFFFu; nvalid = 32;
+#if !defined(JM_NO_PAIR_XCD)
+      // Workgroups go to the 8 XCDs round-robin by linear id.  Dealt so that the two workgroups an XCD receives one after
+      // the other (ids i and i + 8) are horizontally adjacent tiles, each XCD's L2 writes 3072 contiguous bytes per raster
+      // row instead of 1536: c3 +0.7 % (profiles/r03_kernel_experiments.txt; the same mapping costs 4:4:4 0.5 %)
+      if (((gridDim.x * gridDim.y) & 15) == 0) {
+         const uint32_t i = blockIdx.x + gridDim.x * blockIdx.y, k = i & 7, n = i >> 3;
+         const uint32_t j = ((n >> 1) << 4) + (k << 1) + (n & 1);
+         c0 = (j % gridDim.x) * 32; m0 = j / gridDim.x;
+      }
+#endif
    }
    // ---- phase 1 ----
    uint32_t zw[32];
@@ -789,9 +811,9 @@ __global__ void __launch_bounds__(192, JM_R2_WAVES_PER_EU) backend_kernel_rs420(
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       if (l >= 32) s1 = *reinterpret_cast<const u32x4 *>(ul + b1);
       const u32x4 s2 = *reinterpret_cast<const u32x4 *>(ul + b2);
-      if (ok0) __builtin_nontemporal_store(s0, reinterpret_cast<u32x4 *>(ub + o0));
-      if (ok1) __builtin_nontemporal_store(s1, reinterpret_cast<u32x4 *>(ub + o1));
-      if (ok2) __builtin_nontemporal_store(s2, reinterpret_cast<u32x4 *>(ub + o2));
+      if (ok0) rs_store16(ub + o0, s0);
+      if (ok1) rs_store16(ub + o1, s1);
+      if (ok2) rs_store16(ub + o2, s2);
    }
 #endif
 }
