@@ -6,7 +6,8 @@ TAG=$1; WL=${2:-c2}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-end-to-end --workload $WL"
+# --no-other-workloads: the default c2 line also times c3, c4, c5 and one-frame launches (the same kernels under the same names)
+B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-end-to-end --no-other-workloads --workload $WL"
 timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $B --steps 20 > $OUT/trace.log 2>&1 || exit 1
 P="--steps 5 --warmup 1 --prewarm-ms 300"
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -o p -- $B $P > $OUT/pmc_sq.log 2>&1 || exit 2

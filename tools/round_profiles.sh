@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects the round's judged artefacts on ONE GPU box in ONE call: bench lines for every workload, rocprofv3 kernel
-# statistics and PMC passes for c2..c5.  usage: tools/round_profiles.sh r02
-TAG=${1:-r02}
+# statistics and PMC passes for c2..c5.  usage: tools/round_profiles.sh r03
+TAG=${1:-r03}
 mkdir -p gpurun_out/$TAG
 for WL in c2 c3 c4 c5 g1; do
   timeout -k 10 200 python3 bench.py --workload $WL $( [ $WL = c2 ] || echo --no-cpu-baseline --no-end-to-end ) > gpurun_out/$TAG/bench_$WL.json 2> gpurun_out/$TAG/bench_$WL.err || exit 1
