@@ -70,7 +70,13 @@ int  jpeggpu_jpeg_frame_desc(const jpeggpu_jpeg_t *j, jpeggpu_frame_desc_t *desc
 int  jpeggpu_jpeg_scan_info(const jpeggpu_jpeg_t *j, jpeggpu_scan_info_t *info);
 /* Quantisation table <idq> as currently defined (NULL if absent); zigzag order like qtable_t.    */
 const jpeggpu_qtable_t  *jpeggpu_jpeg_qtable(const jpeggpu_jpeg_t *j, int idq);
-/* Host plane of frame component c: QUANTISED zigzag blocks, (blocY*nbH_c + blocX).               */
+/* Host plane of frame component c: QUANTISED zigzag blocks, (blocY*nbH_c + blocX).
+ * NOT a pure accessor for progressive files on a GPU host: DC scans keep coefficient 0 of every block in a packed side
+ * array (1/64 of the plane: what a DC scan uploads), and this call merges that array into the plane before returning it --
+ * it writes through the handle.  So: (1) fetch the pointer AGAIN after every jpeggpu_jpeg_decode_scan (a later DC
+ * refinement scan updates only the side array: coefficient 0 behind an old pointer is stale until the next call);
+ * (2) like every call on a handle it must not run concurrently with another call on the same handle (two readers
+ * would race on the merge).  tests/test_gpu_decode.py::test_plane_pointer_is_refreshed_after_a_dc_refinement_scan.   */
 const jpeggpu_blocl16_t *jpeggpu_jpeg_plane(const jpeggpu_jpeg_t *j, int c);
 int  jpeggpu_jpeg_nb_comments(const jpeggpu_jpeg_t *j);
 const char *jpeggpu_jpeg_comment(const jpeggpu_jpeg_t *j, int i);

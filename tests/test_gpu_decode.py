@@ -202,6 +202,37 @@ def test_per_scan_hand_off_uploads_the_dirty_band(gpu):
     assert sum(1 for s in scans if s[1] == 0) >= 2      # Pillow's script has a DC refinement scan
 
 
+def test_plane_pointer_is_refreshed_after_a_dc_refinement_scan(gpu):
+    """jpeggpu_jpeg_plane on a GPU host merges the packed coefficient-0 array of the DC scans into the host plane when it is
+    CALLED (include/jpeggpu_decode.h): planes fetched after every scan -- before and after the DC refinement scan in
+    particular -- rendered by the oracle give that scan's reference image, and coefficient 0 really changes in the
+    refinement scan (so a pointer kept from before it would be stale)."""
+    from jpeg_decoder_amd import frontend as F
+    from oracle import pyoracle
+    name = "c4_prog422_160x120.jpg"
+    j = F.Jpeg(open(os.path.join(JDIR, name), "rb").read())
+    d = j.desc
+    od = pyoracle.FrameDesc.from_buffer_copy(bytes(d))
+    want = expected_images(EXPECT[name])
+    k, dc_changed = 0, []
+    prev = None
+    while not j.eoi:
+        j.decode_scan()
+        s = j.scan
+        planes = j.planes()                        # fetched again after every scan
+        img = F.pnm_header(d) + pyoracle.oracle.backend_run(od, planes, j.qtables()).tobytes()
+        assert hashlib.sha256(img).hexdigest() == want[k], (k, s.ss, s.se, s.ah)
+        if s.se == 0 and s.ah > 0:                 # the DC refinement scan: one more bit of coefficient 0
+            dc_changed.append(any(not np.array_equal(prev[c][:, 0], planes[c][:, 0]) for c in range(3)))
+            assert all(np.array_equal(prev[c][:, 1:], planes[c][:, 1:]) for c in range(3))
+        prev = planes
+        k += 1
+        if j.eoi:
+            break
+        j.next_header()
+    assert dc_changed and all(dc_changed)
+
+
 def test_handles_on_several_threads_share_the_buffer_cache(gpu):
     """Four threads open, decode, render and close files of a few geometries over and over (each handle on its own
     stream; closed handles hand their pinned and device buffers to the next one of the same size, decode_api.cpp).
