@@ -10,6 +10,7 @@ S420, S444 = ((2, 2), (1, 1), (1, 1)), ((1, 1),) * 3
 bench.WORKLOADS.update({
     "x1": ("2048x1088 4:2:0 (two whole tiles per MCU row: c5's size without linear tiling)", 2048, 1088, S420, 256),
     "x2": ("1920x1080 4:4:4 (linear tiling, 12-byte runs)", 1920, 1080, S444, 128),
+    "x4": ("1920x1080 grayscale (gray linear tiling)", 1920, 1080, ((1, 1),), 512),
     "x3": ("2048x1088 4:4:4 (whole tiles: row-pair units)", 2048, 1088, S444, 128),
 })
 if __name__ == "__main__":
