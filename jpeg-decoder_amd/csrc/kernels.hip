@@ -1,16 +1,20 @@
 // kernels.hip -- HIP kernels of the JPEG pixel back end for gfx950 (MI355X).
 //
-// backend_kernel: the fused path  iquant + izz + idct_opt + upsample + ycc2rgb + raster store.
-//   One workgroup = one tile of T MCUs in one MCU row; one thread = one 8x8 block.
+// The fused path  iquant + izz + idct_opt + upsample + ycc2rgb + raster store.
+//   One workgroup = one tile of T MCUs; one thread = one 8x8 block.
 //   phase 1  each lane loads its own 128-byte blocl16_t record straight into registers (8 x 16 bytes),
 //            dequantises (table words as scalar operands when the wave holds one component), and runs both
 //            1-D passes of the Loeffler IDCT in registers (the inverse zigzag and the transpose between the
 //            passes are register renamings, not data movement), then writes its 8 rows of 8 samples into
 //            the component's u8 raster plane in LDS
-//   phase 2  after the one barrier the threads walk the tile's pixels 4 at a time: replicate-upsampled
-//            chroma fetch (px = x/hf, py = y/vf, src/decoder_utils.c:72-80), packed 16-bit integer colour
-//            conversion, and 12-byte coalesced non-temporal stores into the RGB raster (width cropped,
-//            rows not).
+//   phase 2  after the one barrier: replicate-upsampled chroma fetch (px = x/hf, py = y/vf,
+//            src/decoder_utils.c:72-80), packed 16-bit integer colour conversion, non-temporal raster stores
+//            (width cropped, rows not).
+// Three families:
+//   backend_kernel_rs444   4:4:4 in whole 64-MCU tiles: row-pair units, RGB restaged inside the wave, 16-byte stores
+//   backend_kernel_rs420   4:2:0 in 32-MCU tiles of 192 lanes (Cb and Cr share a wave), same stores, linear tiling
+//   backend_kernel<H,V,T>  everything else (4:2:2, 4:4:0, gray, crops, unaligned rasters, generic factors): runs of 64
+//                          quads per wave with 12-byte stores; backend_kernel_slow for "-f"
 //
 // Compiled with -ffp-contract=off (see jpeg_math.hpp).
 #include <hip/hip_runtime.h>
