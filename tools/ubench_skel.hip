@@ -120,6 +120,28 @@ template <int M> __global__ void __launch_bounds__(192) k(const u32x4 *in, uint8
       }
       return;
    }
+   if (M == 15) {   // rows dealt 3/3/2 (wave w: rows w, w+3, w+6); a wave's first two rows share the middle store (tail of the first,
+      // head of the second), a third row takes one full and one half store: 13 stores per tile, 5/5/3
+      const uint32_t r1 = wave, r2 = wave + 3, r3 = wave + 6;
+      uint8_t *a = tile_out + r1 * stride, *b = tile_out + r2 * stride;
+      __builtin_nontemporal_store(u32x4{w[0][0], w[0][1], w[1][0], w[1][1]}, reinterpret_cast<u32x4 *>(a + lane * 16));
+      __builtin_nontemporal_store(u32x4{w[1][0], w[1][1], w[2][0], w[2][1]}, reinterpret_cast<u32x4 *>(lane < 32 ? a + 1024 + lane * 16 : b + (lane - 32) * 16));
+      __builtin_nontemporal_store(u32x4{w[2][0], w[2][1], w[0][0], w[0][1]}, reinterpret_cast<u32x4 *>(b + 512 + lane * 16));
+      if (r3 < 8) {
+         uint8_t *c = tile_out + r3 * stride;
+         __builtin_nontemporal_store(u32x4{w[3][0], w[3][1], w[4][0], w[4][1]}, reinterpret_cast<u32x4 *>(c + lane * 16));
+         if (lane < 32) __builtin_nontemporal_store(u32x4{w[4][0], w[4][1], w[5][0], w[5][1]}, reinterpret_cast<u32x4 *>(c + 1024 + lane * 16));
+      }
+      return;
+   }
+   if (M == 16) {   // every row on its own: one full and one half store per row, rows dealt 3/3/2: 16 stores per tile
+      for (uint32_t r = wave; r < 8; r += 3) {
+         uint8_t *c = tile_out + r * stride;
+         __builtin_nontemporal_store(u32x4{w[r][0], w[r][1], w[0][0], w[0][1]}, reinterpret_cast<u32x4 *>(c + lane * 16));
+         if (lane < 32) __builtin_nontemporal_store(u32x4{w[1][0], w[1][1], w[r][0], w[r][1]}, reinterpret_cast<u32x4 *>(c + 1024 + lane * 16));
+      }
+      return;
+   }
    if (M == 10 || M == 11) {   // the kernel's skeleton with the wave-private restage: planes interleaved per row pair in LDS
       // (unit u = [Y rows 2u,2u+1 | Cb | Cr] = 3072 contiguous bytes), barrier, then per unit: every lane reads 3 x 16 bytes
       // (16 pixels of each plane), writes 48 bytes of "RGB" back over the unit at 48 * lane, reads 16-byte pieces at
@@ -216,6 +238,8 @@ int main() {
       run<12>("M12 M9 balanced 4/4/4 (unit 3's stores one per wave)", d, o, wgs, 8);
       run<13>("M13 M6's rows of 2048 B with M9's 2/1/1 units", d, o, wgs / 6 * 6, 6);
       run<14>("M14 M9, heavy wave rotating with the workgroup", d, o, wgs, 8);
+      run<15>("M15 rows dealt 3/3/2, pairs share the middle store: 13 stores, 5/5/3", d, o, wgs, 8);
+      run<16>("M16 rows dealt 3/3/2, one full + one half store per row: 16 stores", d, o, wgs, 8);
    }
    return 0;
 }
