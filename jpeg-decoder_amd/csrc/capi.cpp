@@ -350,12 +350,14 @@ int run_device(jpeggpu_ctx_s *ctx, const jpeggpu_frame_desc_t *d, uint32_t nfram
       int rc = ensure_slow_coef(ctx, &p.slow_coef); if (rc) return rc;
    }
    if (nframes > 65535 || d->nbmcuV > 65535) return fail(JPEGGPU_ERR_INVALID_ARG, "nframes / nbmcuV above 65535");
-   // 4:4:4 in full 64-MCU tiles and a 16-byte aligned raster: row-pair units with 16-byte stores (kernels.hip, RS = 1);
-   // the planes then lie in LDS interleaved by row pair
+   // 4:4:4, uncropped, in 64-MCU tiles (whole tiles per MCU row, or linear tiling with an even number of MCUs per row) and a
+   // 16-byte aligned raster: row-pair units with 16-byte stores (kernels.hip, RS = 1); the planes then lie in LDS interleaved
+   // by row pair
    const bool aligned16 = !(((uintptr_t)d_out | out_stride | out_frame_stride) & 15);
-   if (!tuning().no_restage && !p.slow_coef && !p.linear && p.wave_uniform && d->nbcomp == 3 && p.T == 64 && ld.threads == 192 && fast_colour_layout(p) &&
-       p.hf[1] == 1 && p.vf[1] == 1 && d->width == ld.tiles_per_row * 512 && aligned16) {
-      p.restage = 1;
+   if (!tuning().no_restage && !p.slow_coef && p.wave_uniform && d->nbcomp == 3 && p.T == 64 && ld.threads == 192 && fast_colour_layout(p) &&
+       p.hf[1] == 1 && p.vf[1] == 1 && d->width == (uint32_t)d->nbmcuH * 8 && aligned16 &&
+       (p.linear ? (d->nbmcuH % 2 == 0 && d->nbmcuH > 64) : d->nbmcuH % 64 == 0)) {
+      p.restage = p.linear ? 3 : 1;
       p.plane_off[0] = 0; p.plane_off[1] = 1024; p.plane_off[2] = 2048;
    }
    // 4:2:0 (Y 2x2, Cb and Cr 1x1 on one table), uncropped width, 16-byte aligned raster: 32-MCU tiles of 192 lanes, Cb and

@@ -43,7 +43,7 @@ struct BackendParams {
    uint32_t nbmcuH;                // MCUs per MCU row
    uint32_t total_mcus;            // nbmcuH * nbmcuV
    uint32_t restage;               // kernels with restaged 16-byte raster stores (16-byte aligned raster): 1 = backend_kernel_rs444 (4:4:4, whole
-                                   // 64-MCU tiles), 2 = backend_kernel_rs420 (4:2:0, uncropped, 32-MCU tiles, linear when rows are not whole tiles); 0 = general kernel
+                                   // 64-MCU tiles), 3 = backend_kernel_rs444_lin (4:4:4, linear tiling, even MCUs per row), 2 = backend_kernel_rs420 (4:2:0, uncropped, 32-MCU tiles, linear when rows are not whole tiles); 0 = general kernel
    uint32_t qt[4][32];             // quantisation tables, zigzag order, two uint16 per word
 };
 

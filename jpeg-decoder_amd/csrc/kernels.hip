@@ -12,6 +12,7 @@
 //            (width cropped, rows not).
 // Three families:
 //   backend_kernel_rs444   4:4:4 in whole 64-MCU tiles: row-pair units, RGB restaged inside the wave, 16-byte stores
+//   backend_kernel_rs444_lin   the same for other uncropped widths with an even number of MCUs per row (linear tiling)
 //   backend_kernel_rs420   4:2:0 in 32-MCU tiles of 192 lanes (Cb and Cr share a wave), same stores, linear tiling
 //   backend_kernel<H,V,T>  everything else (4:2:2, 4:4:0, gray, crops, unaligned rasters, generic factors): runs of 64
 //                          quads per wave with 12-byte stores; backend_kernel_slow for "-f"
@@ -224,23 +225,36 @@ __device__ __forceinline__ void pixel_phase_runs(const BackendParams &p, const u
 // are in registers by then, and no other wave ever touches it), reads the pieces [1024 s + 16 lane, + 16), s = 0..2,
 // and stores them: 3 x global_store_dwordx4 of 1024 bytes (the middle one ends row 2u and starts row 2u+1).  No
 // workgroup barrier is involved: LDS serves a wave's instructions in order.  4 units on 3 waves: wave 0 takes two.
-// Host side (plan_backend): 64-MCU tiles that all lie inside the frame (width a multiple of 512), raster base and
-// strides multiples of 16.
+// Host side (plan_backend): uncropped width; 64-MCU tiles that all lie inside the frame (width a multiple of 512), or
+// (LIN, linear tiling) an even number of MCUs per row above 64, where a lane's pieces may fall either side of the
+// MCU-row wrap or past the frame's last MCU; raster base and strides multiples of 16.
 constexpr uint32_t kRsRowBytes = 512, kRsPlaneBytes = 1024, kRsUnitBytes = 3072;
 __device__ __forceinline__ uint32_t special_pair_bits(uint32_t cbw, uint32_t crw) {   // has_special_pair before the compare
    const uint32_t t = (cbw ^ 0x1C1C1C1Cu) | (crw ^ 0xE4E4E4E4u);
    return (t - 0x01010101u) & ~t;
 }
-__device__ __forceinline__ void pixel_phase_units444(const BackendParams &p, uint8_t *lds, uint32_t tid, uint32_t tile, uint32_t m, uint32_t frame) {
+template <bool LIN>
+__device__ __forceinline__ void pixel_phase_units444(const BackendParams &p, uint8_t *lds, uint32_t tid, const TileGeom &g, uint32_t frame) {
    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
    const uint32_t l = tid & 63;
    const uint32_t stride = (uint32_t)p.out_stride;
-   uint8_t *tile_out = static_cast<uint8_t *>(p.out) + (size_t)frame * p.out_frame_stride + (size_t)m * 8 * p.out_stride + (size_t)tile * (kRsRowBytes * 3);
-   // where a lane's three 16-byte pieces go, relative to the first byte of the unit's first row
-   const uint32_t o0 = l * 16;
-   const uint32_t o1 = l < 32 ? 1024 + l * 16 : stride + (l - 32) * 16;
-   const uint32_t o2 = stride + 512 + l * 16;
+   const uint32_t band = 8 * stride;
+   uint8_t *tile_out = static_cast<uint8_t *>(p.out) + (size_t)frame * p.out_frame_stride + (size_t)g.m0 * band;
+   // where a lane's three 16-byte pieces go, relative to the first byte of the unit's first row in MCU row m0: byte b of
+   // the tile's 1536-byte row belongs to MCU b / 24; before the wrap (linear tiling) that MCU lies c0 MCUs into MCU row m0,
+   // after it at the start of the next MCU row.  wrapj and nvalid are even (host check), so no piece straddles either.
+   const uint32_t b0 = l * 16, b1 = l < 32 ? 1024 + l * 16 : (l - 32) * 16, b2 = 512 + l * 16;
+   const uint32_t before = g.c0 * 24, after = band - g.wrapj * 24;      // (after is only used under LIN)
+   uint32_t o0 = b0 + before, o1 = b1 + before + (l < 32 ? 0u : stride), o2 = b2 + before + stride;
+   bool ok0 = true, ok1 = true, ok2 = true;
+   if constexpr (LIN) {
+      const uint32_t j0 = b0 / 24, j1 = b1 / 24, j2 = b2 / 24;
+      if (j0 >= g.wrapj) o0 += after - before;
+      if (j1 >= g.wrapj) o1 += after - before;
+      if (j2 >= g.wrapj) o2 += after - before;
+      ok0 = j0 < g.nvalid; ok1 = j1 < g.nvalid; ok2 = j2 < g.nvalid;
+   }
    for (uint32_t u = wave; u < 4; u += 3) {
       uint8_t *ul = lds + u * kRsUnitBytes;
       const uint4 yv = *reinterpret_cast<const uint4 *>(ul + l * 16);
@@ -280,9 +294,9 @@ __device__ __forceinline__ void pixel_phase_units444(const BackendParams &p, uin
       const u32x4 s1 = *reinterpret_cast<const u32x4 *>(ul + 1024 + l * 16);
       const u32x4 s2 = *reinterpret_cast<const u32x4 *>(ul + 2048 + l * 16);
       uint8_t *ub = tile_out + (size_t)(2 * u) * stride;      // wave-uniform
-      rs_store16(ub + o0, s0);
-      rs_store16(ub + o1, s1);
-      rs_store16(ub + o2, s2);
+      if (ok0) rs_store16(ub + o0, s0);
+      if (ok1) rs_store16(ub + o1, s1);
+      if (ok2) rs_store16(ub + o2, s2);
    }
 }
 
@@ -427,7 +441,7 @@ __device__ __forceinline__ void transform_block(const uint32_t (&zw)[32], uint8_
    }
 #pragma unroll
    for (int r = 0; r < 8; r++) {
-      if (RS == 1) *reinterpret_cast<uint2 *>(plane + (r >> 1) * kRsUnitBytes + (r & 1) * kRsRowBytes) = rows[r];   // immediate offsets
+      if (RS == 1 || RS == 3) *reinterpret_cast<uint2 *>(plane + (r >> 1) * kRsUnitBytes + (r & 1) * kRsRowBytes) = rows[r];   // immediate offsets
       else *reinterpret_cast<uint2 *>(plane + r * pitch) = rows[r];
    }
 }
@@ -609,7 +623,7 @@ __device__ __forceinline__ void backend_body(const BackendParams &p) {
    const long long ts3 = __builtin_amdgcn_s_memtime();
 #endif
 #if !defined(JM_DIAG_NOPHASE2)
-   if constexpr (RS == 1) { pixel_phase_units444(p, lds, tid, tile, m, frame); return; }
+   if constexpr (RS == 1 || RS == 3) { pixel_phase_units444<RS == 3>(p, lds, tid, geo, frame); return; }
 #if !defined(JM_NO_RUNS)
    if (HFC != 0 && p.wq_shift >= 6) pixel_phase_runs<(HFC ? HFC : 1), (VFC ? VFC : 1)>(p, lds, tid, nt, geo, frame);
    else
@@ -636,6 +650,8 @@ __global__ void __launch_bounds__(MAXT, JM_WAVES_PER_EU) backend_kernel(const Ba
 
 // 4:4:4 in 64-MCU tiles that all lie inside the frame: pixel phase by row-pair units with 16-byte stores (pixel_phase_units444)
 __global__ void __launch_bounds__(192, JM_RS_WAVES_PER_EU) backend_kernel_rs444(const BackendParams p) { backend_body<1, 1, false, 1>(p); }
+// the same under linear tiling (RS = 3: any even number of MCUs per row above 64): per-lane wrap offsets and predicates
+__global__ void __launch_bounds__(192, JM_RS_WAVES_PER_EU) backend_kernel_rs444_lin(const BackendParams p) { backend_body<1, 1, false, 3>(p); }
 
 // ---- 4:2:0 in 32-MCU tiles with 16-byte stores (RS = 2) -----------------------------------------------------------
 // The general kernel needs 64 MCUs = 384 lanes per tile to keep every wave on one component, which leaves room for
@@ -836,6 +852,7 @@ typedef void (*BackendFn)(const BackendParams);
 static BackendFn pick_kernel(const BackendParams &p, uint32_t threads) {
    if (p.slow_coef) return (BackendFn)backend_kernel_slow;
    if (p.restage == 1) return (BackendFn)backend_kernel_rs444;
+   if (p.restage == 3) return (BackendFn)backend_kernel_rs444_lin;
    if (p.restage == 2) return (BackendFn)backend_kernel_rs420;
 #define JM_PICK(H, V) (threads <= 256 ? (BackendFn)backend_kernel<H, V, 256> : (BackendFn)backend_kernel<H, V, JM_MAX_THREADS>)
    if (fast_colour_layout(p)) {
@@ -859,8 +876,9 @@ hipError_t launch_backend(const BackendParams &p, const LaunchDims &d, hipStream
                           (p.linear ? (d.mcu_rows != 1 || d.tiles_per_row != (p.total_mcus + 31) / 32) : (p.nbmcuH % 32 != 0 || d.tiles_per_row != p.nbmcuH / 32)) ||
                           (((uintptr_t)p.out | p.out_stride | p.out_frame_stride) & 15) || d.lds_bytes < 8 * kR2Unit))
       return hipErrorInvalidConfiguration;
-   if (p.restage == 1 && (p.slow_coef || p.linear || !p.wave_uniform || !fast_colour_layout(p) || p.hf[1] != 1 || p.vf[1] != 1 || p.T != 64 || d.threads != 192 ||
-                          p.width != d.tiles_per_row * 512 || p.plane_off[1] != kRsPlaneBytes || p.plane_off[2] != 2 * kRsPlaneBytes ||
+   if ((p.restage == 1 || p.restage == 3) && ((p.restage == 3) != (p.linear != 0) || p.slow_coef || !p.wave_uniform || !fast_colour_layout(p) || p.hf[1] != 1 || p.vf[1] != 1 || p.T != 64 || d.threads != 192 ||
+                          p.width != p.nbmcuH * 8 || (p.linear ? (p.nbmcuH % 2 != 0 || p.nbmcuH <= 64) : p.nbmcuH != d.tiles_per_row * 64) ||
+                          p.plane_off[1] != kRsPlaneBytes || p.plane_off[2] != 2 * kRsPlaneBytes ||
                           (((uintptr_t)p.out | p.out_stride | p.out_frame_stride) & 15) || d.lds_bytes < 4 * kRsUnitBytes))
       return hipErrorInvalidConfiguration;
    BackendFn k = pick_kernel(p, d.threads);

@@ -237,7 +237,9 @@ def test_kat_frames_through_the_fused_kernels(gpu, knob):
 
 RS_CASES = {
     # (width, height, frames, row padding, apply_iquant)
-    "444": (((1, 1),) * 3, [(512, 8, 1, 0, True), (1024, 24, 3, 16, False), (1536, 13, 2, 48, True), (2048, 40, 1, 7, True), (4096, 16, 2, 0, False)]),
+    "444": (((1, 1),) * 3, [(512, 8, 1, 0, True), (1024, 24, 3, 16, False), (1536, 13, 2, 48, True), (2048, 40, 1, 7, True), (4096, 16, 2, 0, False),
+            # linear tiling (an even number of MCUs per row above 64: backend_kernel_rs444_lin); 520 = 65 MCUs stays on the general kernel
+            (528, 40, 2, 0, True), (1040, 24, 3, 16, False), (1920, 88, 1, 48, True), (1936, 17, 2, 0, True), (520, 16, 1, 0, True)]),
     "420": (((2, 2), (1, 1), (1, 1)), [(512, 16, 1, 0, True), (1024, 40, 3, 16, False), (1920, 1080, 2, 0, True), (1040, 50, 2, 32, True),
                                      (528, 33, 3, 0, False), (2048, 64, 1, 7, True), (8192, 32, 1, 0, True), (496, 16, 1, 0, True)]),
 }
@@ -245,7 +247,8 @@ RS_CASES = {
 
 @pytest.mark.parametrize("layout", sorted(RS_CASES))
 def test_restaged_kernels_with_16_byte_stores(gpu, layout):
-    """4:4:4 frames made of whole 64-MCU tiles take backend_kernel_rs444, uncropped 4:2:0 frames backend_kernel_rs420 (32-MCU
+    """4:4:4 frames made of whole 64-MCU tiles take backend_kernel_rs444 (other uncropped widths with an even number of MCUs
+    per row: backend_kernel_rs444_lin, linear tiling), uncropped 4:2:0 frames backend_kernel_rs420 (32-MCU
     tiles, Cb and Cr sharing a wave, linear tiling when an MCU row is not a whole number of tiles) -- both with the RGB restaged
     inside the wave and 16-byte stores, and only when the raster is 16-byte aligned; anything else, and JPEGGPU_NO_RESTAGE, the
     general kernel.  Both against the oracle: several frames per launch, padded rows, the special chroma pair, both iquant modes."""
@@ -256,7 +259,7 @@ def test_restaged_kernels_with_16_byte_stores(gpu, layout):
         gd = helpers.to_gpu_desc(gpu, d)
         nb = [helpers.plane_shape(d, c)[0] for c in range(3)]
         host = [pyoracle.synth_blocks(nb[c] * nf, 4400 + 3 * w + c, 0, 0 if aq else 1) for c in range(3)]
-        if w == 1024:      # the special pair (cb, cr) = (28, 228) under a ramp of luma values
+        if w in (1024, 1040):      # the special pair (cb, cr) = (28, 228) under a ramp of luma values
             for c in range(3):
                 host[c][:nb[c], :] = 0
             host[0][:nb[0], 0] = ((np.arange(nb[0]) % 256) - 128) * 8
