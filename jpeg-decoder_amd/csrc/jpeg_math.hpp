@@ -19,6 +19,14 @@
 
 #define JM_HD __host__ __device__ __forceinline__
 
+// Phase markers for the instruction table of tools/isa_phases.py (diagnostic builds only, -DJM_PHASE_MARKS): a comment in
+// the ISA between two scheduling barriers, so that every instruction can be attributed to the phase it was written in.
+#if defined(JM_PHASE_MARKS) && defined(__HIP_DEVICE_COMPILE__)
+#define JM_MARK(name) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; JM_PHASE " name ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define JM_MARK(name) do { } while (0)
+#endif
+
 namespace jpegmath {
 
 // ---- Loeffler constants -------------------------------------------------------------------
@@ -304,8 +312,10 @@ JM_HD void idct8_row_pk_biased(f32x2 P0, f32x2 P1, f32x2 P2, f32x2 P3, float (&o
 #define JM_RP_PAIR { 0, 2, 1, 3, 0, 3, 1, 2 }
 #define JM_RP_HALF { 0, 0, 0, 0, 1, 1, 1, 1 }
 JM_HD void idct_block_rp(f32x2 (&p1)[4][8], uint2 (&row)[8]) {
+   JM_MARK("pass1");
 #pragma unroll
    for (int cp = 0; cp < 4; cp++) idct8(p1[cp]);
+   JM_MARK("pass2_bias_pack");
 #pragma unroll
    for (int r = 0; r < 8; r++) {
       float u[8];

@@ -256,6 +256,7 @@ __device__ __forceinline__ void pixel_phase_units444(const BackendParams &p, uin
       ok0 = j0 < g.nvalid; ok1 = j1 < g.nvalid; ok2 = j2 < g.nvalid;
    }
    for (uint32_t u = wave; u < 4; u += 3) {
+      JM_MARK("unit_lds_reads");
       uint8_t *ul = lds + u * kRsUnitBytes;
       const uint4 yv = *reinterpret_cast<const uint4 *>(ul + l * 16);
       const uint4 cb = *reinterpret_cast<const uint4 *>(ul + kRsPlaneBytes + l * 16);
@@ -266,9 +267,11 @@ __device__ __forceinline__ void pixel_phase_units444(const BackendParams &p, uin
 #pragma unroll
       for (int k = 0; k < 4; k++) { w[k][0] = yy[k]; w[k][1] = cbw[k]; w[k][2] = crw[k]; }
 #else
+      JM_MARK("unit_special_pair_test");
       const uint32_t sp = (special_pair_bits(cbw[0], crw[0]) | special_pair_bits(cbw[1], crw[1]) | special_pair_bits(cbw[2], crw[2]) |
                            special_pair_bits(cbw[3], crw[3])) & 0x80808080u;
       if (__builtin_expect(__any(sp != 0), 0)) {
+         JM_MARK("unit_exact_colour_cold");
          // exact per-pixel form (the y-dependent green offset of (cb,cr) = (28,228))
 #pragma unroll
          for (int k = 0; k < 4; k++) {
@@ -279,10 +282,12 @@ __device__ __forceinline__ void pixel_phase_units444(const BackendParams &p, uin
             w[k][0] = px[0] | (px[1] << 24); w[k][1] = (px[1] >> 8) | (px[2] << 16); w[k][2] = (px[2] >> 16) | (px[3] << 8);
          }
       } else {
+         JM_MARK("unit_colour");
 #pragma unroll
          for (int k = 0; k < 4; k++) rgb_quad_pk(yy[k], chroma_pairs<1>(cbw[k] ^ 0x80808080u, crw[k] ^ 0x80808080u), w[k]);
       }
 #endif
+      JM_MARK("unit_restage");
       // every lane's samples are in registers (the values above depend on all three reads) before the first write is issued
       *reinterpret_cast<u32x4 *>(ul + l * 48) = u32x4{w[0][0], w[0][1], w[0][2], w[1][0]};
       *reinterpret_cast<u32x4 *>(ul + l * 48 + 16) = u32x4{w[1][1], w[1][2], w[2][0], w[2][1]};
@@ -293,10 +298,12 @@ __device__ __forceinline__ void pixel_phase_units444(const BackendParams &p, uin
       const u32x4 s0 = *reinterpret_cast<const u32x4 *>(ul + l * 16);
       const u32x4 s1 = *reinterpret_cast<const u32x4 *>(ul + 1024 + l * 16);
       const u32x4 s2 = *reinterpret_cast<const u32x4 *>(ul + 2048 + l * 16);
+      JM_MARK("unit_stores");
       uint8_t *ub = tile_out + (size_t)(2 * u) * stride;      // wave-uniform
       if (ok0) rs_store16(ub + o0, s0);
       if (ok1) rs_store16(ub + o1, s1);
       if (ok2) rs_store16(ub + o2, s2);
+      JM_MARK("unit_loop");
    }
 }
 
@@ -428,6 +435,7 @@ __device__ __forceinline__ void transform_block(const uint32_t (&zw)[32], uint8_
    uint2 rows[8];
    {
       f32x2 mtx[4][8];
+      JM_MARK("izz_int16_to_float");
       izz_rp(zw, mtx);   // pass-1 pairing (0,4)(2,6)(1,7)(3,5): pass 2 stays packed within a row
 #if defined(JM_DIAG_NOIDCT)
 #pragma unroll
@@ -439,6 +447,7 @@ __device__ __forceinline__ void transform_block(const uint32_t (&zw)[32], uint8_
       idct_block_rp(mtx, rows);
 #endif
    }
+   JM_MARK("lds_plane_writes");
 #pragma unroll
    for (int r = 0; r < 8; r++) {
       if (RS == 1 || RS == 3) *reinterpret_cast<uint2 *>(plane + (r >> 1) * kRsUnitBytes + (r & 1) * kRsRowBytes) = rows[r];   // immediate offsets
@@ -541,12 +550,14 @@ __device__ __forceinline__ void backend_body(const BackendParams &p) {
                             (size_t)m * vs * nbH * 128;      // uniform; two MCU rows of a plane are < 2^32 bytes
       const uint4 *src = reinterpret_cast<const uint4 *>(base + (((r2 ? vs : 0u) + by) * nbH + col) * 128u);
       uint4 v[8];
+      JM_MARK("record_loads");
 #pragma unroll
       for (int i = 0; i < 8; i++) v[i] = src[i];   // NOT non-temporal: a lane's 8 loads share one line (nt: 1.6x slower)
 #if defined(JM_DIAG_STAMP)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       ts1 = __builtin_amdgcn_s_memtime();
 #endif
+      JM_MARK("iquant");
       if (p.apply_iquant) {
          const uint32_t *q = p.qt[p.idq[c]];
 #pragma unroll
@@ -558,6 +569,7 @@ __device__ __forceinline__ void backend_body(const BackendParams &p) {
 #pragma unroll
          for (int i = 0; i < 8; i++) { zw[4 * i] = v[i].x; zw[4 * i + 1] = v[i].y; zw[4 * i + 2] = v[i].z; zw[4 * i + 3] = v[i].w; }
       }
+      JM_MARK("lds_address");
       pitch = bw * 8;
       plane = lds + p.plane_off[c] + (by * 8) * pitch + bxl * 8;
       active = true;        // B is a multiple of 64 here
@@ -613,6 +625,7 @@ __device__ __forceinline__ void backend_body(const BackendParams &p) {
       if constexpr (SLOW) transform_block_slow(zw, plane, pitch, p.slow_coef);
       else transform_block<RS>(zw, plane, pitch);
    }
+   JM_MARK("barrier");
 
 #if defined(JM_DIAG_STAMP)
    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -623,6 +636,7 @@ __device__ __forceinline__ void backend_body(const BackendParams &p) {
    const long long ts3 = __builtin_amdgcn_s_memtime();
 #endif
 #if !defined(JM_DIAG_NOPHASE2)
+   JM_MARK("pixel_setup");
    if constexpr (RS == 1 || RS == 3) { pixel_phase_units444<RS == 3>(p, lds, tid, geo, frame); return; }
 #if !defined(JM_NO_RUNS)
    if (HFC != 0 && p.wq_shift >= 6) pixel_phase_runs<(HFC ? HFC : 1), (VFC ? VFC : 1)>(p, lds, tid, nt, geo, frame);
@@ -718,8 +732,10 @@ __global__ void __launch_bounds__(192, JM_R2_WAVES_PER_EU) backend_kernel_rs420(
          idq = p.idq[1];
       }
       uint4 v[8];
+      JM_MARK("record_loads");
 #pragma unroll
       for (int i = 0; i < 8; i++) v[i] = src[i];
+      JM_MARK("iquant");
       if (p.apply_iquant) {
          const uint32_t *q = p.qt[idq];
 #pragma unroll
@@ -736,6 +752,7 @@ __global__ void __launch_bounds__(192, JM_R2_WAVES_PER_EU) backend_kernel_rs420(
       uint2 rows[8];
       {
          f32x2 mtx[4][8];
+         JM_MARK("izz_int16_to_float");
          izz_rp(zw, mtx);
 #if defined(JM_DIAG_NOIDCT)
 #pragma unroll
@@ -749,14 +766,17 @@ __global__ void __launch_bounds__(192, JM_R2_WAVES_PER_EU) backend_kernel_rs420(
       }
       // Y wave w, block row r -> raster row R = 8 w + r of the tile: unit R >> 1, its row R & 1; chroma row r -> unit r.
       // Both are pl + (r >> 1) * U + (r & 1) * V with wave-uniform U, V (lanes 32..63 of the chroma wave: kR2Cb + 256 + ... = kR2Cr + ...)
+      JM_MARK("lds_plane_writes");
       const uint32_t U = wave < 2 ? kR2Unit : 2 * kR2Unit, V = wave < 2 ? 512u : kR2Unit;
       uint8_t *pl = lds + (wave < 2 ? wave * (4 * kR2Unit) : kR2Cb) + (tid & 63) * 8;
 #pragma unroll
       for (int r = 0; r < 8; r++) *reinterpret_cast<uint2 *>(pl + ((r >> 1) * U + (r & 1) * V)) = rows[r];
    }
+   JM_MARK("barrier");
    __syncthreads();
 #if !defined(JM_DIAG_NOPHASE2)
    // ---- phase 2 ----
+   JM_MARK("pixel_setup");
    const uint32_t l = tid & 63;
    const uint32_t stride = (uint32_t)p.out_stride;
    const uint32_t band = 16 * stride;
@@ -777,6 +797,7 @@ __global__ void __launch_bounds__(192, JM_R2_WAVES_PER_EU) backend_kernel_rs420(
    }
    uint8_t *tile_out = static_cast<uint8_t *>(p.out) + (size_t)frame * p.out_frame_stride + (size_t)m0 * band;
    for (uint32_t u = wave; u < 8; u += 3) {
+      JM_MARK("unit_lds_reads");
       uint8_t *ul = lds + u * kR2Unit;
       const uint2 ya = *reinterpret_cast<const uint2 *>(ul + l * 8);
       const uint2 yb = *reinterpret_cast<const uint2 *>(ul + 512 + l * 8);
@@ -787,7 +808,9 @@ __global__ void __launch_bounds__(192, JM_R2_WAVES_PER_EU) backend_kernel_rs420(
       wa[0][0] = ya.x; wa[0][1] = cbw; wa[0][2] = crw; wa[1][0] = ya.y; wa[1][1] = cbw; wa[1][2] = crw;
       wb[0][0] = yb.x; wb[0][1] = cbw; wb[0][2] = crw; wb[1][0] = yb.y; wb[1][1] = cbw; wb[1][2] = crw;
 #else
+      JM_MARK("unit_special_pair_test");
       if (__builtin_expect(__any(has_special_pair(cbw, crw)), 0)) {
+         JM_MARK("unit_exact_colour_cold");
 #pragma unroll
          for (int q = 0; q < 2; q++) {
             uint32_t pa[4], pb[4];
@@ -802,12 +825,14 @@ __global__ void __launch_bounds__(192, JM_R2_WAVES_PER_EU) backend_kernel_rs420(
             wb[q][0] = pb[0] | (pb[1] << 24); wb[q][1] = (pb[1] >> 8) | (pb[2] << 16); wb[q][2] = (pb[2] >> 16) | (pb[3] << 8);
          }
       } else {
+         JM_MARK("unit_colour");
          const uint32_t cbs = cbw ^ 0x80808080u, crs = crw ^ 0x80808080u;
          const ChromaPairs oa = chroma_pairs<2>(cbs, crs), ob = chroma_pairs<2>(cbs >> 16, crs >> 16);
          rgb_quad_pk(ya.x, oa, wa[0]); rgb_quad_pk(ya.y, ob, wa[1]);
          rgb_quad_pk(yb.x, oa, wb[0]); rgb_quad_pk(yb.y, ob, wb[1]);
       }
 #endif
+      JM_MARK("unit_restage");
       uint8_t *ub = tile_out + (size_t)(2 * u) * stride;      // wave-uniform
       // row 2u through the unit's own 1536 bytes (every lane's samples are in registers: wa / wb depend on all four reads)
       *reinterpret_cast<uint2 *>(ul + l * 24) = make_uint2(wa[0][0], wa[0][1]);
@@ -831,9 +856,11 @@ __global__ void __launch_bounds__(192, JM_R2_WAVES_PER_EU) backend_kernel_rs420(
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       if (l >= 32) s1 = *reinterpret_cast<const u32x4 *>(ul + b1);
       const u32x4 s2 = *reinterpret_cast<const u32x4 *>(ul + b2);
+      JM_MARK("unit_stores");
       if (ok0) rs_store16(ub + o0, s0);
       if (ok1) rs_store16(ub + o1, s1);
       if (ok2) rs_store16(ub + o2, s2);
+      JM_MARK("unit_loop");
    }
 #endif
 }
