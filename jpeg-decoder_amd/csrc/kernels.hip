@@ -234,10 +234,8 @@ __device__ __forceinline__ uint32_t special_pair_bits(uint32_t cbw, uint32_t crw
    return (t - 0x01010101u) & ~t;
 }
 template <bool LIN>
-__device__ __forceinline__ void pixel_phase_units444(const BackendParams &p, uint8_t *lds, uint32_t tid, const TileGeom &g, uint32_t frame) {
+__device__ __forceinline__ void pixel_phase_units444(const BackendParams &p, uint8_t *lds, uint32_t wave, uint32_t l, const TileGeom &g, uint32_t frame) {
    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-   const uint32_t l = tid & 63;
    const uint32_t stride = (uint32_t)p.out_stride;
    const uint32_t band = 8 * stride;
    uint8_t *tile_out = static_cast<uint8_t *>(p.out) + (size_t)frame * p.out_frame_stride + (size_t)g.m0 * band;
@@ -448,6 +446,9 @@ __device__ __forceinline__ void transform_block(const uint32_t (&zw)[32], uint8_
 #endif
    }
    JM_MARK("lds_plane_writes");
+   // RS kernels pass the wave's plane; the lane's column is added here, from a fresh read of the lane id, so that no
+   // per-lane value but the block itself is live across the transform (72 VGPRs)
+   if (RS == 1 || RS == 3) plane += __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) * 8;
 #pragma unroll
    for (int r = 0; r < 8; r++) {
       if (RS == 1 || RS == 3) *reinterpret_cast<uint2 *>(plane + (r >> 1) * kRsUnitBytes + (r & 1) * kRsRowBytes) = rows[r];   // immediate offsets
@@ -509,7 +510,7 @@ __device__ __forceinline__ void backend_body(const BackendParams &p) {
    // [blockIdx.x * T, + T) of the frame in raster order
    uint32_t tile = blockIdx.x, m = blockIdx.y;
    TileGeom geo;
-   if (p.linear) {
+   if (RS == 1 ? false : (RS == 3 ? true : p.linear != 0)) {
       const uint32_t g0 = tile * p.T;
       geo.m0 = g0 / p.nbmcuH;
       geo.c0 = g0 - geo.m0 * p.nbmcuH;
@@ -523,6 +524,7 @@ __device__ __forceinline__ void backend_body(const BackendParams &p) {
    const long long ts0 = __builtin_amdgcn_s_memtime();
    const long long tr0 = __builtin_amdgcn_s_memrealtime();
 #endif
+   uint32_t rs_wave = 0;   // RS kernels: the wave's index in the workgroup (scalar)
    uint32_t zw[32];        // the block's record, dequantised in place
    uint8_t *plane;         // first sample of the block in its component's LDS plane
    uint32_t pitch;         // bytes per row of that plane
@@ -530,6 +532,41 @@ __device__ __forceinline__ void backend_body(const BackendParams &p) {
 #if defined(JM_DIAG_STAMP)
    long long ts1;
 #endif
+   if constexpr (RS == 1 || RS == 3) {
+      // 4:4:4 in 64-MCU tiles of 192 lanes: wave = component, lane = block = MCU of the tile; the only per-lane part of a
+      // record's address is its column (and, under linear tiling, the MCU row it falls in)
+      const uint32_t c = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
+      rs_wave = c;
+      const uint32_t nbH = p.nbH[c];
+      uint32_t rec;                                            // record index from the start of the plane's MCU row m
+      if constexpr (RS == 1) rec = geo.c0 + l;
+      else {
+         const bool r2 = l >= geo.wrapj && l < geo.nvalid;
+         rec = r2 ? nbH + l - geo.wrapj : min(geo.c0 + l, nbH - 1);   // lanes past the frame's last MCU read a valid block: never stored
+      }
+      const uint8_t *base = static_cast<const uint8_t *>(p.coef[c]) + (size_t)frame * p.coef_frame_stride[c] + (size_t)m * nbH * 128;
+      const uint4 *src = reinterpret_cast<const uint4 *>(base + rec * 128u);
+      uint4 v[8];
+      JM_MARK("record_loads");
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[i] = src[i];
+      JM_MARK("iquant");
+      if (p.apply_iquant) {
+         const uint32_t *q = p.qt[p.idq[c]];
+#pragma unroll
+         for (int i = 0; i < 8; i++) {
+            zw[4 * i] = iquant_word(v[i].x, q[4 * i]); zw[4 * i + 1] = iquant_word(v[i].y, q[4 * i + 1]);
+            zw[4 * i + 2] = iquant_word(v[i].z, q[4 * i + 2]); zw[4 * i + 3] = iquant_word(v[i].w, q[4 * i + 3]);
+         }
+      } else {
+#pragma unroll
+         for (int i = 0; i < 8; i++) { zw[4 * i] = v[i].x; zw[4 * i + 1] = v[i].y; zw[4 * i + 2] = v[i].z; zw[4 * i + 3] = v[i].w; }
+      }
+      JM_MARK("lds_address");
+      pitch = 512;
+      plane = lds + c * kRsPlaneBytes;       // + lane * 8 in transform_block
+      active = true;
+   } else
 #if !defined(JM_NO_UNIFORM_PATH)
    if (RS != 0 || p.wave_uniform) {
       const uint32_t wb = __builtin_amdgcn_readfirstlane(tid);   // first block of this wave
@@ -637,7 +674,12 @@ __device__ __forceinline__ void backend_body(const BackendParams &p) {
 #endif
 #if !defined(JM_DIAG_NOPHASE2)
    JM_MARK("pixel_setup");
-   if constexpr (RS == 1 || RS == 3) { pixel_phase_units444<RS == 3>(p, lds, tid, geo, frame); return; }
+   if constexpr (RS == 1 || RS == 3) {
+      // the lane id is read again (2 instructions) instead of being kept in a register across phase 1: at 72 VGPRs it would be spilled
+      const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      pixel_phase_units444<RS == 3>(p, lds, rs_wave, lane, geo, frame);
+      return;
+   }
 #if !defined(JM_NO_RUNS)
    if (HFC != 0 && p.wq_shift >= 6) pixel_phase_runs<(HFC ? HFC : 1), (VFC ? VFC : 1)>(p, lds, tid, nt, geo, frame);
    else
