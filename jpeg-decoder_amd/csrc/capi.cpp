@@ -304,6 +304,7 @@ void plan_backend(const jpeggpu_frame_desc_t *d, const jpeggpu_qtable_t *const q
    for (int c = 0; c < d->nbcomp; c++) { const uint32_t s = log2_exact(d->comp[c].hs); p.hs_shift[c] = s == 0xFFu ? 0 : s; pow2 = pow2 && s != 0xFFu; }
    p.mcu_q_shift = pow2 ? log2_exact((uint32_t)d->max_h * 2) : 0;
    p.nbmcuH = d->nbmcuH; p.total_mcus = d->nbmcuH * d->nbmcuV;
+   p.inv_nbmcuH = (uint32_t)((1ull << 32) / (d->nbmcuH < 2 ? 2u : (uint32_t)d->nbmcuH));
    ld.tiles_per_row = (d->nbmcuH + T - 1) / T;
    ld.mcu_rows = d->nbmcuV;
    // Linear tiling: when an MCU row is not a whole number of tiles (1920 pixels of 4:2:0 = 120 MCUs = 1.875 tiles) the

@@ -42,8 +42,9 @@ struct BackendParams {
    uint32_t linear;                // 1: a tile is T consecutive MCUs of the FRAME in raster order (grid.x = tiles per frame, grid.y = 1)
    uint32_t nbmcuH;                // MCUs per MCU row
    uint32_t total_mcus;            // nbmcuH * nbmcuV
+   uint32_t inv_nbmcuH;            // floor(2^32 / max(nbmcuH, 2)): linear tiling divides by nbmcuH on the scalar unit (kernels.hip, mcu_row_of)
    uint32_t restage;               // kernels with restaged 16-byte raster stores (16-byte aligned raster): 1 = backend_kernel_rs444 (4:4:4, whole
-                                   // 64-MCU tiles), 3 = backend_kernel_rs444_lin (4:4:4, linear tiling, even MCUs per row), 2 = backend_kernel_rs420 (4:2:0, uncropped, 32-MCU tiles, linear when rows are not whole tiles); 0 = general kernel
+                                   // 64-MCU tiles), 3 = backend_kernel_rs444_lin (4:4:4, linear tiling, even MCUs per row), 2 = backend_kernel_rs420 / _rs420_lin (4:2:0, uncropped, 32-MCU tiles, linear when rows are not whole tiles); 0 = general kernel
    uint32_t qt[4][32];             // quantisation tables, zigzag order, two uint16 per word
 };
 

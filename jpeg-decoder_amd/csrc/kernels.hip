@@ -13,7 +13,8 @@
 // Three families:
 //   backend_kernel_rs444   4:4:4 in whole 64-MCU tiles: row-pair units, RGB restaged inside the wave, 16-byte stores
 //   backend_kernel_rs444_lin   the same for other uncropped widths with an even number of MCUs per row (linear tiling)
-//   backend_kernel_rs420   4:2:0 in 32-MCU tiles of 192 lanes (Cb and Cr share a wave), same stores, linear tiling
+//   backend_kernel_rs420 / _rs420_lin   4:2:0 in 32-MCU tiles of 192 lanes (Cb and Cr share a wave), same stores; whole tiles
+//                          per MCU row / linear tiling
 //   backend_kernel<H,V,T>  everything else (4:2:2, 4:4:0, gray, crops, unaligned rasters, generic factors): runs of 64
 //                          quads per wave with 12-byte stores; backend_kernel_slow for "-f"
 //
@@ -426,6 +427,15 @@ __device__ __forceinline__ void pixel_phase(const BackendParams &p, const uint8_
    }
 }
 
+// g / nbmcuH for a scalar g < total_mcus: one s_mul_hi_u32 with the host's floor(2^32 / nbmcuH) and one correction step
+// (the estimate is short by at most 1), so that the quotient never touches the vector unit
+__device__ __forceinline__ uint32_t mcu_row_of(const BackendParams &p, uint32_t g) {
+   uint32_t q = __umulhi(g, p.inv_nbmcuH);
+   if (g - q * p.nbmcuH >= p.nbmcuH) q++;
+   return q;
+}
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
 // Phase 1 of one block: both IDCT passes in registers, 8 rows of 8 samples to the component's u8 plane in
 // LDS.  zw = the block's 64 coefficients after iquant, zigzag order, two int16 per word.
 template <int RS>
@@ -448,7 +458,7 @@ __device__ __forceinline__ void transform_block(const uint32_t (&zw)[32], uint8_
    JM_MARK("lds_plane_writes");
    // RS kernels pass the wave's plane; the lane's column is added here, from a fresh read of the lane id, so that no
    // per-lane value but the block itself is live across the transform (72 VGPRs)
-   if (RS == 1 || RS == 3) plane += __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) * 8;
+   if (RS == 1 || RS == 3) plane += lane_id() * 8;
 #pragma unroll
    for (int r = 0; r < 8; r++) {
       if (RS == 1 || RS == 3) *reinterpret_cast<uint2 *>(plane + (r >> 1) * kRsUnitBytes + (r & 1) * kRsRowBytes) = rows[r];   // immediate offsets
@@ -512,7 +522,7 @@ __device__ __forceinline__ void backend_body(const BackendParams &p) {
    TileGeom geo;
    if (RS == 1 ? false : (RS == 3 ? true : p.linear != 0)) {
       const uint32_t g0 = tile * p.T;
-      geo.m0 = g0 / p.nbmcuH;
+      geo.m0 = mcu_row_of(p, g0);
       geo.c0 = g0 - geo.m0 * p.nbmcuH;
       geo.wrapj = p.nbmcuH - geo.c0;
       geo.nvalid = min(p.T, p.total_mcus - g0);
@@ -575,7 +585,7 @@ __device__ __forceinline__ void backend_body(const BackendParams &p) {
       const uint32_t r = tid - p.boff[c];
       uint32_t by = 0;
       if (vs > 1) by = (uint32_t)(r >= bw) + (uint32_t)(r >= 2 * bw) + (uint32_t)(r >= 3 * bw);
-      const uint32_t bxl = r - by * bw;
+      const uint32_t bxl = r - __umul24(by, bw);            // 24-bit multiplies (full rate): by <= 3, bw <= 1024
       // the block's MCU row: the tile's first one, or (linear tiling) the next one for the MCUs after the wrap point
       const uint32_t hsh = p.hs_shift[c];
       const uint32_t j = bxl >> hsh;                        // MCU of the tile this block belongs to
@@ -585,7 +595,7 @@ __device__ __forceinline__ void backend_body(const BackendParams &p) {
       col = min(col, nbH - 1);                              // lanes right of the plane / past the frame's last MCU read a valid block: never stored
       const uint8_t *base = static_cast<const uint8_t *>(p.coef[c]) + (size_t)frame * p.coef_frame_stride[c] +
                             (size_t)m * vs * nbH * 128;      // uniform; two MCU rows of a plane are < 2^32 bytes
-      const uint4 *src = reinterpret_cast<const uint4 *>(base + (((r2 ? vs : 0u) + by) * nbH + col) * 128u);
+      const uint4 *src = reinterpret_cast<const uint4 *>(base + (__umul24((r2 ? vs : 0u) + by, nbH) + col) * 128u);   // nbH < 2^18
       uint4 v[8];
       JM_MARK("record_loads");
 #pragma unroll
@@ -676,7 +686,7 @@ __device__ __forceinline__ void backend_body(const BackendParams &p) {
    JM_MARK("pixel_setup");
    if constexpr (RS == 1 || RS == 3) {
       // the lane id is read again (2 instructions) instead of being kept in a register across phase 1: at 72 VGPRs it would be spilled
-      const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      const uint32_t lane = lane_id();
       pixel_phase_units444<RS == 3>(p, lds, rs_wave, lane, geo, frame);
       return;
    }
@@ -726,57 +736,47 @@ constexpr uint32_t kR2Unit = 1536, kR2Cb = 1024, kR2Cr = 1280;
 #ifndef JM_R2_WAVES_PER_EU
 #define JM_R2_WAVES_PER_EU 6
 #endif
-__global__ void __launch_bounds__(192, JM_R2_WAVES_PER_EU) backend_kernel_rs420(const BackendParams p) {
-   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-   const uint32_t tid = threadIdx.x;
-   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-   const uint32_t frame = blockIdx.z;
-   uint32_t m0, c0, wrapj, nvalid;
-   if (p.linear) {
-      const uint32_t g0 = blockIdx.x * 32;
-      m0 = g0 / p.nbmcuH; c0 = g0 - m0 * p.nbmcuH; wrapj = p.nbmcuH - c0; nvalid = min(32u, p.total_mcus - g0);
-   } else {
-      m0 = blockIdx.y; c0 = blockIdx.x * 32; wrapj = 0x7FFFFFFFu; nvalid = 32;
-#if !defined(JM_NO_PAIR_XCD)
-      // Workgroups go to the 8 XCDs round-robin by linear id.  Dealt so that the two workgroups an XCD receives one after
-      // the other (ids i and i + 8) are horizontally adjacent tiles, each XCD's L2 writes 3072 contiguous bytes per raster
-      // row instead of 1536: c3 +0.7 % (profiles/r03_kernel_experiments.txt; the same mapping costs 4:4:4 0.5 %)
-      if (((gridDim.x * gridDim.y) & 15) == 0) {
-         const uint32_t i = blockIdx.x + gridDim.x * blockIdx.y, k = i & 7, n = i >> 3;
-         const uint32_t j = ((n >> 1) << 4) + (k << 1) + (n & 1);
-         c0 = (j % gridDim.x) * 32; m0 = j / gridDim.x;
-      }
-#endif
-   }
-   // ---- phase 1 ----
+// Phase 1 of one wave of the 4:2:0 kernel.  Y (CHROMA = false): block row `wave` of the MCU row, 64 blocks, a scalar base
+// plus a 32-bit lane offset.  CHROMA: lanes 0-31 Cb, 32-63 Cr, one 64-bit base per half.  LDS: Y wave w, block row r ->
+// raster row R = 8 w + r of the tile: unit R >> 1, its row R & 1; chroma row r -> unit r: pl + (r >> 1) * U + (r & 1) * V
+// with U, V = 1536, 512 (Y) / 3072, 1536 (chroma; lanes 32..63: kR2Cb + 256 + ... = kR2Cr + ...).
+template <bool LIN, bool CHROMA>
+__device__ __forceinline__ void rs420_phase1(const BackendParams &p, uint8_t *lds, uint32_t wave, uint32_t frame, uint32_t m0, uint32_t c0,
+                                             uint32_t wrapj, uint32_t nvalid) {
    uint32_t zw[32];
    {
-      const uint32_t l = tid & 63;
-      const uint4 *src;
+      const uint32_t l = threadIdx.x & 63;
+      uint4 v[8];
       uint32_t idq;
-      if (wave < 2) {      // Y: block row `wave` of the MCU row, 64 blocks
-         const uint32_t nbH = p.nbH[0], j = l >> 1;
-         const bool r2 = j >= wrapj && j < nvalid;
-         uint32_t col = r2 ? l - (wrapj << 1) : (c0 << 1) + l;
-         col = min(col, nbH - 1);
-         const uint8_t *base = static_cast<const uint8_t *>(p.coef[0]) + (size_t)frame * p.coef_frame_stride[0] + (size_t)m0 * 2 * nbH * 128;
-         src = reinterpret_cast<const uint4 *>(base + (((r2 ? 2u : 0u) + wave) * nbH + col) * 128u);
+      if constexpr (!CHROMA) {
+         const uint32_t nbH = p.nbH[0];
+         uint32_t rec;                                      // record index from the start of block row (2 m0 + wave) of the plane
+         if constexpr (LIN) {
+            const uint32_t j = l >> 1;
+            const bool r2 = j >= wrapj && j < nvalid;
+            rec = r2 ? 2 * nbH + l - 2 * wrapj : min(2 * c0 + l, nbH - 1);   // lanes past the frame's last MCU read a valid block: never stored
+         } else rec = 2 * c0 + l;
+         const uint8_t *base = static_cast<const uint8_t *>(p.coef[0]) + (size_t)frame * p.coef_frame_stride[0] + ((size_t)m0 * 2 + wave) * nbH * 128;
+         const uint4 *src = reinterpret_cast<const uint4 *>(base + rec * 128u);
+         JM_MARK("record_loads");
+#pragma unroll
+         for (int i = 0; i < 8; i++) v[i] = src[i];
          idq = p.idq[0];
-      } else {             // Cb | Cr
+      } else {
          const uint32_t nbH = p.nbH[1], j = l & 31;
-         const bool r2 = j >= wrapj && j < nvalid;
-         uint32_t col = r2 ? j - wrapj : c0 + j;
-         col = min(col, nbH - 1);
+         uint32_t rec;
+         if constexpr (LIN) {
+            const bool r2 = j >= wrapj && j < nvalid;
+            rec = r2 ? nbH + j - wrapj : min(c0 + j, nbH - 1);
+         } else rec = c0 + j;
          const uint8_t *b1 = static_cast<const uint8_t *>(p.coef[1]) + (size_t)frame * p.coef_frame_stride[1] + (size_t)m0 * nbH * 128;
          const uint8_t *b2 = static_cast<const uint8_t *>(p.coef[2]) + (size_t)frame * p.coef_frame_stride[2] + (size_t)m0 * nbH * 128;
-         src = reinterpret_cast<const uint4 *>((l < 32 ? b1 : b2) + ((r2 ? nbH : 0u) + col) * 128u);
+         const uint4 *src = reinterpret_cast<const uint4 *>((l < 32 ? b1 : b2) + rec * 128u);
+         JM_MARK("record_loads");
+#pragma unroll
+         for (int i = 0; i < 8; i++) v[i] = src[i];
          idq = p.idq[1];
       }
-      uint4 v[8];
-      JM_MARK("record_loads");
-#pragma unroll
-      for (int i = 0; i < 8; i++) v[i] = src[i];
       JM_MARK("iquant");
       if (p.apply_iquant) {
          const uint32_t *q = p.qt[idq];
@@ -790,36 +790,63 @@ __global__ void __launch_bounds__(192, JM_R2_WAVES_PER_EU) backend_kernel_rs420(
          for (int i = 0; i < 8; i++) { zw[4 * i] = v[i].x; zw[4 * i + 1] = v[i].y; zw[4 * i + 2] = v[i].z; zw[4 * i + 3] = v[i].w; }
       }
    }
+   uint2 rows[8];
    {
-      uint2 rows[8];
-      {
-         f32x2 mtx[4][8];
-         JM_MARK("izz_int16_to_float");
-         izz_rp(zw, mtx);
+      f32x2 mtx[4][8];
+      JM_MARK("izz_int16_to_float");
+      izz_rp(zw, mtx);
 #if defined(JM_DIAG_NOIDCT)
 #pragma unroll
-         for (int r = 0; r < 8; r++) { float u[8];
+      for (int r = 0; r < 8; r++) { float u[8];
 #pragma unroll
-            for (int c2 = 0; c2 < 8; c2++) u[c2] = (c2 & 1) ? mtx[c2 >> 1][r].y : mtx[c2 >> 1][r].x;
-            rows[r] = pack_row(u); }
+         for (int c2 = 0; c2 < 8; c2++) u[c2] = (c2 & 1) ? mtx[c2 >> 1][r].y : mtx[c2 >> 1][r].x;
+         rows[r] = pack_row(u); }
 #else
-         idct_block_rp(mtx, rows);
+      idct_block_rp(mtx, rows);
 #endif
-      }
-      // Y wave w, block row r -> raster row R = 8 w + r of the tile: unit R >> 1, its row R & 1; chroma row r -> unit r.
-      // Both are pl + (r >> 1) * U + (r & 1) * V with wave-uniform U, V (lanes 32..63 of the chroma wave: kR2Cb + 256 + ... = kR2Cr + ...)
-      JM_MARK("lds_plane_writes");
-      const uint32_t U = wave < 2 ? kR2Unit : 2 * kR2Unit, V = wave < 2 ? 512u : kR2Unit;
-      uint8_t *pl = lds + (wave < 2 ? wave * (4 * kR2Unit) : kR2Cb) + (tid & 63) * 8;
-#pragma unroll
-      for (int r = 0; r < 8; r++) *reinterpret_cast<uint2 *>(pl + ((r >> 1) * U + (r & 1) * V)) = rows[r];
    }
+   JM_MARK("lds_plane_writes");
+   // the lane id is read again here: nothing per-lane but the block itself lives across the transform
+   uint8_t *pl = lds + (CHROMA ? kR2Cb : wave * (4 * kR2Unit)) + lane_id() * 8;
+#pragma unroll
+   for (int r = 0; r < 8; r++)
+      *reinterpret_cast<uint2 *>(pl + (CHROMA ? (r >> 1) * (2 * kR2Unit) + (r & 1) * kR2Unit : (r >> 1) * kR2Unit + (r & 1) * 512u)) = rows[r];
+}
+
+template <bool LIN>
+__device__ __forceinline__ void rs420_body(const BackendParams &p) {
+   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+   const uint32_t frame = blockIdx.z;
+   uint32_t m0, c0, wrapj = 0x7FFFFFFFu, nvalid = 32;
+   if constexpr (LIN) {
+      const uint32_t g0 = blockIdx.x * 32;
+      m0 = mcu_row_of(p, g0); c0 = g0 - m0 * p.nbmcuH; wrapj = p.nbmcuH - c0; nvalid = min(32u, p.total_mcus - g0);
+   } else {
+      m0 = blockIdx.y; c0 = blockIdx.x * 32;
+#if !defined(JM_NO_PAIR_XCD)
+      // Workgroups go to the 8 XCDs round-robin by linear id.  Dealt so that the two workgroups an XCD receives one after
+      // the other (ids i and i + 8) are horizontally adjacent tiles, each XCD's L2 writes 3072 contiguous bytes per raster
+      // row instead of 1536: c3 +0.7 % (profiles/r03_kernel_experiments.txt; the same mapping costs 4:4:4 0.5 %)
+      const uint32_t X = gridDim.x;
+      if (((X * gridDim.y) & 15) == 0) {
+         const uint32_t i = blockIdx.x + X * blockIdx.y, k = i & 7, n = i >> 3;
+         const uint32_t j = ((n >> 1) << 4) + (k << 1) + (n & 1);
+         if ((X & (X - 1)) == 0) { const uint32_t sh = (uint32_t)__builtin_ctz(X); m0 = j >> sh; c0 = (j & (X - 1)) * 32; }   // scalar shifts
+         else { m0 = j / X; c0 = (j - m0 * X) * 32; }
+      }
+#endif
+   }
+   // ---- phase 1: the Y waves and the chroma wave each run a copy of their own (scalar branch) ----
+   if (wave < 2) rs420_phase1<LIN, false>(p, lds, wave, frame, m0, c0, wrapj, nvalid);
+   else rs420_phase1<LIN, true>(p, lds, wave, frame, m0, c0, wrapj, nvalid);
    JM_MARK("barrier");
    __syncthreads();
 #if !defined(JM_DIAG_NOPHASE2)
    // ---- phase 2 ----
    JM_MARK("pixel_setup");
-   const uint32_t l = tid & 63;
+   const uint32_t l = lane_id();
    const uint32_t stride = (uint32_t)p.out_stride;
    const uint32_t band = 16 * stride;
    // the three pieces of a lane: (row of the unit, byte offset in the tile's 1536-byte row)
@@ -827,7 +854,7 @@ __global__ void __launch_bounds__(192, JM_R2_WAVES_PER_EU) backend_kernel_rs420(
    const uint32_t r1 = l < 32 ? 0u : stride;
    uint32_t o0, o1, o2;
    bool ok0 = true, ok1 = true, ok2 = true;
-   if (p.linear) {
+   if constexpr (LIN) {
       // MCU of a piece = byte / 48; before the wrap it lies c0 MCUs into MCU row m0, after it at the start of the next one
       const uint32_t j0 = b0 / 48, j1 = b1 / 48, j2 = b2 / 48;
       const uint32_t before = c0 * 48, after = band - wrapj * 48;
@@ -906,6 +933,8 @@ __global__ void __launch_bounds__(192, JM_R2_WAVES_PER_EU) backend_kernel_rs420(
    }
 #endif
 }
+__global__ void __launch_bounds__(192, JM_R2_WAVES_PER_EU) backend_kernel_rs420(const BackendParams p) { rs420_body<false>(p); }
+__global__ void __launch_bounds__(192, JM_R2_WAVES_PER_EU) backend_kernel_rs420_lin(const BackendParams p) { rs420_body<true>(p); }
 
 // the "-f" variant: generic pixel phase, no occupancy target (the direct transform keeps the block in 64 VGPRs)
 __global__ void __launch_bounds__(JM_MAX_THREADS) backend_kernel_slow(const BackendParams p) { backend_body<0, 0, true>(p); }
@@ -922,7 +951,7 @@ static BackendFn pick_kernel(const BackendParams &p, uint32_t threads) {
    if (p.slow_coef) return (BackendFn)backend_kernel_slow;
    if (p.restage == 1) return (BackendFn)backend_kernel_rs444;
    if (p.restage == 3) return (BackendFn)backend_kernel_rs444_lin;
-   if (p.restage == 2) return (BackendFn)backend_kernel_rs420;
+   if (p.restage == 2) return p.linear ? (BackendFn)backend_kernel_rs420_lin : (BackendFn)backend_kernel_rs420;
 #define JM_PICK(H, V) (threads <= 256 ? (BackendFn)backend_kernel<H, V, 256> : (BackendFn)backend_kernel<H, V, JM_MAX_THREADS>)
    if (fast_colour_layout(p)) {
       const uint32_t h = p.hf[1], v = p.vf[1];
