@@ -357,6 +357,14 @@ JM_HD void dequant_izz(const uint32_t (&zw)[32], const uint32_t (&qw)[32], float
 JM_HD uint32_t iquant_word(uint32_t zw, uint32_t qw) {
    return __builtin_bit_cast(uint32_t, (jm_us2)(__builtin_bit_cast(jm_us2, zw) * __builtin_bit_cast(jm_us2, qw)));
 }
+// The converted values are made opaque to the optimiser: it would otherwise rewrite the first butterflies of pass 1,
+// (float)a +- (float)b, as (float)(a +- b) (exact for int16, so legal) -- one integer add and one conversion per OUTPUT where
+// the packed form needs one conversion per input and one v_pk_add_f32 per two outputs: 16 instructions more per block.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(JM_NO_OPAQUE_CVT)
+#define JM_OPAQUE(f) asm("" : "+v"(f))
+#else
+#define JM_OPAQUE(f) do { } while (0)
+#endif
 JM_HD void izz_rp(const uint32_t (&zw)[32], f32x2 (&p1)[4][8]) {
    constexpr uint8_t ZR[64] = JM_ZZ_ROWS;
    constexpr uint8_t ZC[64] = JM_ZZ_COLS;
@@ -364,7 +372,8 @@ JM_HD void izz_rp(const uint32_t (&zw)[32], f32x2 (&p1)[4][8]) {
    constexpr uint8_t PH[8] = JM_RP_HALF;
 #pragma unroll
    for (int i = 0; i < 32; i++) {
-      const float f0 = (float)(int)(short)(zw[i] & 0xFFFF), f1 = (float)(int)(short)(zw[i] >> 16);
+      float f0 = (float)(int)(short)(zw[i] & 0xFFFF), f1 = (float)(int)(short)(zw[i] >> 16);
+      JM_OPAQUE(f0); JM_OPAQUE(f1);
       if (PH[ZC[2 * i]]) p1[PP[ZC[2 * i]]][ZR[2 * i]].y = f0; else p1[PP[ZC[2 * i]]][ZR[2 * i]].x = f0;
       if (PH[ZC[2 * i + 1]]) p1[PP[ZC[2 * i + 1]]][ZR[2 * i + 1]].y = f1; else p1[PP[ZC[2 * i + 1]]][ZR[2 * i + 1]].x = f1;
    }
