@@ -61,6 +61,16 @@ __device__ __forceinline__ void rs_store16(uint8_t *dst, rs_u32x4 v) {
    *reinterpret_cast<rs_u32x4 *>(dst) = v;
 #endif
 }
+// The same store as scalar base + 32-bit lane offset (the compiler adds the two in 64 bits on the vector unit instead: three
+// v_lshl_add_u64 and three zeroed registers per unit).  base must be wave-uniform.  The s_nop covers the wait states a
+// following overwrite of the data registers needs (the compiler's hazard recogniser does not look into asm).
+__device__ __forceinline__ void rs_store16_s(const uint8_t *base, uint32_t off, rs_u32x4 v) {
+#if JM_RS_NT && !defined(JM_NO_SADDR_STORE)
+   asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(off), "v"(v), "s"(base) : "memory");
+#else
+   rs_store16(const_cast<uint8_t *>(base) + off, v);
+#endif
+}
 
 struct __attribute__((packed, aligned(4))) rgb4_t { uint32_t a, b, c; };
 
@@ -299,9 +309,9 @@ __device__ __forceinline__ void pixel_phase_units444(const BackendParams &p, uin
       const u32x4 s2 = *reinterpret_cast<const u32x4 *>(ul + 2048 + l * 16);
       JM_MARK("unit_stores");
       uint8_t *ub = tile_out + (size_t)(2 * u) * stride;      // wave-uniform
-      if (ok0) rs_store16(ub + o0, s0);
-      if (ok1) rs_store16(ub + o1, s1);
-      if (ok2) rs_store16(ub + o2, s2);
+      if (ok0) rs_store16_s(ub, o0, s0);
+      if (ok1) rs_store16_s(ub, o1, s1);
+      if (ok2) rs_store16_s(ub, o2, s2);
       JM_MARK("unit_loop");
    }
 }
@@ -926,9 +936,9 @@ __device__ __forceinline__ void rs420_body(const BackendParams &p) {
       if (l >= 32) s1 = *reinterpret_cast<const u32x4 *>(ul + b1);
       const u32x4 s2 = *reinterpret_cast<const u32x4 *>(ul + b2);
       JM_MARK("unit_stores");
-      if (ok0) rs_store16(ub + o0, s0);
-      if (ok1) rs_store16(ub + o1, s1);
-      if (ok2) rs_store16(ub + o2, s2);
+      if (ok0) rs_store16_s(ub, o0, s0);
+      if (ok1) rs_store16_s(ub, o1, s1);
+      if (ok2) rs_store16_s(ub, o2, s2);
       JM_MARK("unit_loop");
    }
 #endif
