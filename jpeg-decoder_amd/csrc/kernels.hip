@@ -733,8 +733,8 @@ __global__ void __launch_bounds__(192, JM_RS_WAVES_PER_EU) backend_kernel_rs444_
 // The general kernel needs 64 MCUs = 384 lanes per tile to keep every wave on one component, which leaves room for
 // four workgroups per CU.  Here a tile is 32 MCUs = 192 lanes: waves 0 and 1 hold the two block rows of Y (64 blocks
 // each), wave 2 holds Cb in lanes 0..31 and Cr in lanes 32..63 -- both are 1x1 components of equal geometry and (host
-// check) share a quantisation table, so the two differ in one 64-bit base address per lane.  Free of the generic
-// paths the kernel fits 72 VGPRs: 9 workgroups per CU.
+// check) share a quantisation table, so the two differ in one 64-bit base address per lane.  The kernel needs
+// 76-80 VGPRs (6 waves per SIMD = 8 workgroups per CU; forced to 72 it spills, and spills cost more than the ninth workgroup).
 // LDS: unit u = raster rows 2u, 2u+1 of the tile = [Y row 2u (512 B) | Y row 2u+1 (512 B) | Cb row u (256 B) | Cr row u
 // (256 B)] = 1536 bytes, 8 units.  Phase 2: a unit belongs to one wave; lane l reads 8 pixels x 2 rows (two ds_read_b64
 // of Y, one dword of each chroma plane), converts, and the unit's 1536 bytes become the staging of ONE raster row at a
